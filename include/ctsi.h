@@ -1,0 +1,214 @@
+/*
+ * ctsi.h — C ABI of the MI355X (gfx950) CT slice-interpolation engine.
+ *
+ * This is the drop-in boundary underneath the reference's Python module surface
+ * (models.* / inference.*).  The reference has no FFI of its own: every entry point
+ * below replaces a PyTorch op family that the reference calls on its hot path, cited
+ * as `reference file:line`.  The Python host (video-to-video-diffusion_amd/) binds
+ * these with ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - extern "C", plain pointers / sizes / ints, no torch or C++ types.
+ *  - every function returns 0 on success, <0 on error; ctsi_last_error() returns a
+ *    thread-local message.  Nothing throws.
+ *  - no entry point allocates device memory, synchronises the stream or the device:
+ *    the caller passes all buffers (query sizes with the *_bytes/_floats helpers).
+ *    All launches go to the `stream` argument (a hipStream_t passed as void*), so a
+ *    caller may capture any sequence of calls into a hipGraph (ctsi_graph_*).
+ *  - activations inside the engine are bf16, channels-last ("NDHWC": n, d, h, w, c with
+ *    c fastest).  The API boundary tensors of the reference are fp32 NCDHW; the two
+ *    conversion entry points sit at that boundary.  Accumulation, GroupNorm statistics,
+ *    the time embedding and the DDIM/DDPM state are fp32.
+ */
+#ifndef CTSI_H
+#define CTSI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTSI_OK 0
+#define CTSI_ERR_INVALID (-1)
+#define CTSI_ERR_UNSUPPORTED (-2)
+#define CTSI_ERR_HIP (-3)
+
+/* library / error handling ------------------------------------------------------------ */
+int ctsi_version(void);
+const char* ctsi_last_error(void);
+/* 1 when a HIP device is visible to this process, 0 otherwise (never raises). */
+int ctsi_device_available(void);
+
+/* boundary layout conversion ---------------------------------------------------------- *
+ * fp32 NCDHW (reference API tensors, models/model.py:252-259) <-> bf16 NDHWC (engine).
+ * `c_total`/`c_off` let the caller write a channel slice of a wider NDHWC tensor
+ * (used for torch.cat([x, c], dim=1), models/unet3d.py:372).                            */
+int ctsi_ncdhw_f32_to_ndhwc_bf16(const float* src, void* dst, int n, int c, int d, int h, int w,
+                                 int c_total, int c_off, void* stream);
+int ctsi_ndhwc_bf16_to_ncdhw_f32(const void* src, float* dst, int n, int c, int d, int h, int w,
+                                 void* stream);
+/* fp32 NDHWC <-> fp32 NCDHW (sampler state z lives as fp32 NDHWC inside the engine). */
+int ctsi_ncdhw_f32_to_ndhwc_f32(const float* src, float* dst, int n, int c, int d, int h, int w,
+                                void* stream);
+int ctsi_ndhwc_f32_to_ncdhw_f32(const float* src, float* dst, int n, int c, int d, int h, int w,
+                                void* stream);
+
+/* convolution family ------------------------------------------------------------------ *
+ * One gather-GEMM MFMA kernel serves nn.Conv3d k=3 p=1 (models/unet3d.py:56,96,257,331;
+ * models/vae.py:27,45,134,188), k=1 (unet3d.py:102,152-153; vae.py:137,161),
+ * k=(3,4,4) s=(1,2,2) p=1 (unet3d.py:204-207; vae.py:65-68) and
+ * nn.ConvTranspose3d k=(3,4,4) s=(1,2,2) p=1 (unet3d.py:218-221; vae.py:86-89).
+ *
+ * A plan is a host-only opaque object (no device memory) describing one layer at one
+ * input shape.  The input may be the channel concatenation of two NDHWC tensors
+ * (c1 + c2 channels; c2 = 0 for a single source) so torch.cat along channels
+ * (unet3d.py:372, 401) is never materialised.                                           */
+typedef struct ctsi_conv_plan ctsi_conv_plan;
+
+typedef struct ctsi_conv_desc {
+    int transposed;      /* 0: Conv3d, 1: ConvTranspose3d                                   */
+    int kd, kh, kw;      /* kernel size                                                     */
+    int sh, sw;          /* stride in H, W (depth stride is always 1 on this path)         */
+    int pd, ph, pw;      /* padding                                                         */
+    int n, c1, c2;       /* batch, channels of source 1 and source 2 (c2 may be 0)        */
+    int cout;
+    int di, hi, wi;      /* input spatial size                                             */
+} ctsi_conv_desc;
+
+/* epilogue description for ctsi_conv_fwd */
+typedef struct ctsi_conv_out {
+    void* y;             /* output tensor                                                   */
+    int mode;            /* 0: bf16 NDHWC, channel stride = cout_stride, offset c_off      */
+                         /* 1: fp32 with explicit element strides (sn, sc, sd, sh, sw)     */
+    int cout_stride;     /* mode 0: channels per voxel of y (>= c_off + cout)              */
+    int c_off;           /* mode 0: first channel written                                   */
+    long long sn, sc, sd, sh, sw; /* mode 1 strides, in elements                           */
+    int act;             /* 0: none, 1: tanh (models/vae.py:203)                           */
+    float* colsum;       /* optional: per-tile column sums for a following GroupNorm
+                            ([2][ctsi_conv_plan_tiles()][cout_pad] floats), or NULL       */
+} ctsi_conv_out;
+
+int ctsi_conv_plan_create(ctsi_conv_plan** plan, const ctsi_conv_desc* desc);
+/* the weight tensor carries only `cin_w` (< c1+c2) input channels; the remaining activation
+ * channels are layout padding (the 1-channel CT volume is stored with 8 channels).       */
+int ctsi_conv_plan_set_weight_cin(ctsi_conv_plan* plan, int cin_w);
+void ctsi_conv_plan_destroy(ctsi_conv_plan* plan);
+/* output spatial size of the layer */
+int ctsi_conv_plan_out_dims(const ctsi_conv_plan* plan, int* d_out, int* h_out, int* w_out);
+/* bytes of the packed bf16 weight image this plan consumes */
+size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* plan);
+/* number of row tiles (all samples, all parity classes) and padded cout: sizes the colsum slab */
+int ctsi_conv_plan_tiles(const ctsi_conv_plan* plan);
+int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* plan);
+int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* plan);
+/* algorithmic FLOPs (2*MAC, dense direct convolution) of one forward of this layer */
+double ctsi_conv_plan_flops(const ctsi_conv_plan* plan);
+/* re-layout reference weights (fp32, PyTorch layout: Conv3d (cout,cin,kd,kh,kw),
+ * ConvTranspose3d (cin,cout,kd,kh,kw)) into the kernel's bf16 [class][cout_pad][K] image. */
+int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* plan, const float* w_f32, void* packed,
+                                void* stream);
+/* y = conv(cat(x1,x2)) + bias, optional activation, optional GroupNorm column sums. */
+int ctsi_conv_fwd(const ctsi_conv_plan* plan, const void* x1, const void* x2, const void* packed_w,
+                  const float* bias, const ctsi_conv_out* out, void* stream);
+
+/* GroupNorm (+SiLU, +time bias, +residual) ----------------------------------------------- *
+ * nn.GroupNorm(eps=1e-5, affine) + SiLU + the ResBlock tail of models/unet3d.py:70-74,
+ * 116-133 and models/vae.py:31-35, 50-56, 72-76, 93-97.
+ * Statistics are two-stage: per-tile column sums (from the conv epilogue, or from
+ * ctsi_gn_colsum for tensors that no conv produced) -> ctsi_gn_finalize -> (sum, sumsq)
+ * per (sample, group) in fp64 -> ctsi_gn_apply.                                          */
+int ctsi_gn_colsum(const void* x_bf16, float* colsum, int n, int c, int d, int h, int w,
+                   int* tiles_per_sample, void* stream);
+int ctsi_gn_colsum_tiles(int d, int h, int w);
+/* sums[n][g][2] (double) += over tiles/columns.  `sums` must be zeroed by the caller.
+ * nclass > 1: tiles of class k of sample i start at (k*n + i)*tiles_per_sample.          */
+int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c, int c_pad, int groups,
+                     int tiles_per_sample, int nclass, void* stream);
+/* y = [silu]( gn(x)*gamma+beta ) [+ tbias[n][c]] [+ residual] ; [silu] again if silu_post */
+/* tbias row used for sample i: (step_ptr ? *step_ptr : 0) * n + i  (row length tbias_stride) */
+int ctsi_gn_apply(const void* x_bf16, void* y_bf16, const double* sums, const float* gamma,
+                  const float* beta, int n, int c, int d, int h, int w, int groups, float eps,
+                  int silu_pre, const float* tbias, int tbias_stride, const int* step_ptr,
+                  const void* residual_bf16, int silu_post, void* stream);
+
+/* TemporalAttention (models/unet3d.py:136-194) --------------------------------------------- *
+ * The reference's second einsum 'bhqk,bhvc->bhqc' contracts k and v independently, so the
+ * module equals proj_out(rowsum(softmax) * sum_t V_t) + x with rowsum(softmax) == 1.
+ * mode 0 (fast) uses that identity; mode 1 (exact) additionally evaluates
+ * rowsum(softmax(q k^T * hd^-0.5)) in fp32 per (position, head, query) and multiplies by it. */
+/* pass 1: GroupNorm column sums of x and depth sums S[n][h][w][c] = sum_d x (fp32) */
+int ctsi_attn_depthsum(const void* x_bf16, float* depthsum, float* colsum, int n, int c, int d,
+                       int h, int w, void* stream);
+int ctsi_attn_depthsum_tiles(int c, int h, int w);
+/* pass 2: xhat_sum = gamma*rstd*(S - D*mean) + D*beta as bf16 (n, 1, h, w, c) */
+int ctsi_attn_normsum(const float* depthsum, const double* sums, const float* gamma,
+                      const float* beta, void* out_bf16, int n, int c, int d, int h, int w,
+                      int groups, float eps, void* stream);
+/* pass 3 (after a 1x1x1 conv of xhat_sum with W_proj*W_v): y = x + p[n][h][w][c] broadcast over d.
+ * rowsum (exact mode, fp32 [n][d][h][w][heads]) may be NULL (== 1).                       */
+int ctsi_attn_broadcast_add(const void* x_bf16, const void* p_bf16, const float* rowsum, int heads,
+                            void* y_bf16, int n, int c, int d, int h, int w, void* stream);
+/* exact mode helper: rowsum[n][d][h][w][head] = sum_k softmax_k(q.k * hd^-0.5) from
+ * qk = conv1x1(gn(x)) restricted to the q and k thirds (bf16 NDHWC with 2*c channels). */
+int ctsi_attn_softmax_rowsum(const void* qk_bf16, float* rowsum, int n, int c, int d, int h, int w,
+                             int heads, void* stream);
+
+/* time embedding (models/unet3d.py:18-48 and the per-block Linear of :88-91, 123-125) ------- *
+ * temb = Linear2(SiLU(Linear1(sincos(t))));  tbias[r][o] = W_all[o] . SiLU(temb[r]) + b_all[o]
+ * for the concatenation of every ResBlock's time_mlp.1 (`total_out` rows of W_all).
+ * `t_rows` holds `rows` timestep values on the device (all steps x batch of a sampling loop are
+ * embedded in one call, the schedule being known up front); scratch = rows*(dim+2*time_dim) floats. */
+int ctsi_time_embed_fwd(const int* t_rows, int rows, int dim, int time_dim, const float* w1,
+                        const float* b1, const float* w2, const float* b2, const float* w_all,
+                        const float* b_all, int total_out, float* scratch, float* tbias_out,
+                        void* stream);
+
+/* trilinear depth upsample (F.interpolate(..., 'trilinear', align_corners=False) with h, w
+ * unchanged: models/model.py:284-289, 191-196).  fp32 NCDHW in -> bf16 NDHWC channel slice
+ * [c_off, c_off+c) of a c_total-channel tensor, plus an optional fp32 NCDHW copy.            */
+int ctsi_trilinear_depth_fwd(const float* src_f32_ncdhw, void* dst_bf16_ndhwc, int n, int c,
+                             int d_in, int d_out, int h, int w, int c_total, int c_off,
+                             float* dst_f32_ncdhw, void* stream);
+
+/* sampler updates --------------------------------------------------------------------------- *
+ * DDIM (inference/sampler.py:294-334) and DDPM (models/diffusion.py:270-338) elementwise
+ * updates with the reference's epsilons, clamps and nan_to_num guards folded in.
+ * coef is a device table of 8 floats per step (see video-to-video-diffusion_amd/sampler.py);
+ * the row used is coef[*step_ptr] (row 0 when step_ptr is NULL).  z (fp32 NDHWC) is updated in
+ * place and a bf16 copy is written into channels [c_off, c_off+c) of the U-Net input tensor.
+ * noise (fp32 NCDHW, the layout torch.randn_like(z) has) may be NULL.
+ * ctsi_step_advance increments the device-side step counter (last node of a step graph).   */
+int ctsi_ddim_step(float* z, const float* eps, const float* noise_ncdhw, void* zin_bf16,
+                   int c_total, int c_off, const float* coef, const int* step_ptr, int n, int c,
+                   int d, int h, int w, void* stream);
+int ctsi_ddpm_step(float* z, const float* eps, const float* noise_ncdhw, void* zin_bf16,
+                   int c_total, int c_off, const float* coef, const int* step_ptr, int n, int c,
+                   int d, int h, int w, void* stream);
+int ctsi_step_advance(int* step_ptr, void* stream);
+/* x <- nan_to_num(x, nan=0, posinf=1, neginf=-1) on a flat fp32 buffer (model.py:262-341) */
+int ctsi_nan_to_num_f32(float* x, long long count, void* stream);
+
+/* hipMemsetAsync on the engine stream (zeroing GroupNorm accumulators / padded channels);
+ * capturable as a memset node.                                                              */
+int ctsi_memset_async(void* ptr, int value, size_t bytes, void* stream);
+
+/* hipGraph helpers (one captured graph per denoising step) -------------------------------- */
+typedef struct ctsi_graph ctsi_graph;
+int ctsi_graph_begin_capture(void* stream);
+int ctsi_graph_end_capture(void* stream, ctsi_graph** graph);
+int ctsi_graph_launch(ctsi_graph* graph, void* stream);
+void ctsi_graph_destroy(ctsi_graph* graph);
+
+/* timing helpers used by bench.py (HIP events on the engine's own stream) ----------------- */
+typedef struct ctsi_event ctsi_event;
+int ctsi_event_create(ctsi_event** ev);
+int ctsi_event_record(ctsi_event* ev, void* stream);
+int ctsi_event_elapsed_ms(ctsi_event* start, ctsi_event* stop, float* ms);
+void ctsi_event_destroy(ctsi_event* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTSI_H */

@@ -1,0 +1,237 @@
+// TemporalAttention of the reference (models/unet3d.py:136-194) as HBM-bound passes.
+//
+// As written, the module computes out = einsum('bhqk,bhvc->bhqc', softmax(q k^T / sqrt(hd)), v):
+// k and v are independent summation indices, so out[q] = rowsum(softmax)[q] * sum_t V_t and
+// rowsum(softmax) == 1.  With V = W_v gn(x) + b_v (1x1x1 conv, linear):
+//     module(x) = x + W_p ( W_v * sum_d gn(x)_d + D*b_v ) + b_p          (broadcast over depth)
+// Pass 1 (attn_depthsum_kernel) reads x once: GroupNorm column sums + S = sum_d x.
+// Pass 2 (attn_normsum_kernel) forms sum_d gn(x)_d = gamma*rstd*(S - D*mean) + D*beta.
+// The two pointwise matrices are folded into one 1x1x1 conv (conv_mfma.hip) by the host.
+// Pass 3 (attn_broadcast_add_kernel) adds the (h,w,c) result back over depth.
+// Exact mode evaluates rowsum(softmax(q k^T * hd^-0.5)) in fp32 (attn_softmax_rowsum_kernel) and
+// scales the broadcast term with it, reproducing the einsum term by term.
+#include "ctsi_internal.h"
+
+__device__ __forceinline__ void unpack8a(const uint4 v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+#define ATTN_POS_PER_BLOCK_ROUNDS 4
+
+// grid: (tiles, n); block 256.  Each thread owns one 8-channel chunk of `rounds` positions.
+__global__ void __launch_bounds__(256)
+attn_depthsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ depthsum, float* __restrict__ colsum,
+                     int n_total, int c, int d, int hw, int tps) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_red = reinterpret_cast<float*>(smem_raw);  // [rows_par][c][2]
+    const int cpr = c >> 3;
+    const int rows_par = 256 / cpr;
+    const int tid = threadIdx.x;
+    const int q = tid % cpr, rl = tid / cpr;
+    const int tile = blockIdx.x, nb = blockIdx.y;
+    const int ppb = rows_par * ATTN_POS_PER_BLOCK_ROUNDS;
+    float c1[8], c2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c1[k] = c2[k] = 0.0f;
+    if (rl < rows_par) {
+        for (int rnd = 0; rnd < ATTN_POS_PER_BLOCK_ROUNDS; ++rnd) {
+            const int pos = tile * ppb + rnd * rows_par + rl;
+            if (pos >= hw) break;
+            float s[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] = 0.0f;
+            const bf16_t* base = x + (((long long)nb * d) * hw + pos) * c + q * 8;
+            for (int dd = 0; dd < d; ++dd) {
+                float f[8];
+                unpack8a(*reinterpret_cast<const uint4*>(base + (long long)dd * hw * c), f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    s[k] += f[k];
+                    c2[k] += f[k] * f[k];
+                }
+            }
+            float* o = depthsum + ((long long)nb * hw + pos) * c + q * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(s[4], s[5], s[6], s[7]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c1[k] += s[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s_red[(rl * c + q * 8 + k) * 2 + 0] = c1[k];
+            s_red[(rl * c + q * 8 + k) * 2 + 1] = c2[k];
+        }
+    }
+    __syncthreads();
+    for (int col = tid; col < c; col += 256) {
+        float t1 = 0.0f, t2 = 0.0f;
+        for (int r = 0; r < rows_par; ++r) {
+            t1 += s_red[(r * c + col) * 2 + 0];
+            t2 += s_red[(r * c + col) * 2 + 1];
+        }
+        const long long tg = (long long)nb * tps + tile;
+        const long long slab = (long long)n_total * tps * c;
+        colsum[tg * c + col] = t1;
+        colsum[slab + tg * c + col] = t2;
+    }
+}
+
+extern "C" int ctsi_attn_depthsum_tiles(int c, int h, int w) {
+    if (c < 8 || c % 8 != 0 || c > 2048) return 0;
+    const int rows_par = 256 / (c / 8);
+    const int ppb = rows_par * ATTN_POS_PER_BLOCK_ROUNDS;
+    return (h * w + ppb - 1) / ppb;
+}
+
+extern "C" int ctsi_attn_depthsum(const void* x, float* depthsum, float* colsum, int n, int c, int d, int h,
+                                  int w, void* stream) {
+    CTSI_CHECK_ARG(x && depthsum && colsum, "ctsi_attn_depthsum: null argument");
+    CTSI_CHECK_ARG(c % 8 == 0 && c >= 8 && c <= 2048, "ctsi_attn_depthsum: bad c=%d", c);
+    const int tps = ctsi_attn_depthsum_tiles(c, h, w);
+    const int rows_par = 256 / (c / 8);
+    const size_t lds = (size_t)rows_par * c * 2 * sizeof(float);
+    hipLaunchKernelGGL(attn_depthsum_kernel, dim3(tps, n), dim3(256), lds, (hipStream_t)stream,
+                       (const bf16_t*)x, depthsum, colsum, n, c, d, h * w, tps);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// xhat_sum[n][pos][ch] = gamma*rstd*(S - D*mean) + D*beta   (bf16)
+__global__ void __launch_bounds__(256)
+attn_normsum_kernel(const float* __restrict__ depthsum, const double* __restrict__ sums,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ out,
+                    int c, int d, long long hw, int groups, float eps, long long total) {
+    const int cpg = c / groups;
+    const double cnt = (double)cpg * (double)d * (double)hw;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int ch = (int)(e % c);
+        const long long nb = e / (hw * c);
+        const int g = ch / cpg;
+        const double m = sums[(nb * groups + g) * 2 + 0] / cnt;
+        double var = sums[(nb * groups + g) * 2 + 1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float v = gamma[ch] * rstd * (depthsum[e] - (float)d * (float)m) + (float)d * beta[ch];
+        out[e] = f32_to_bf16(v);
+    }
+}
+
+extern "C" int ctsi_attn_normsum(const float* depthsum, const double* sums, const float* gamma,
+                                 const float* beta, void* out, int n, int c, int d, int h, int w, int groups,
+                                 float eps, void* stream) {
+    CTSI_CHECK_ARG(depthsum && sums && gamma && beta && out, "ctsi_attn_normsum: null argument");
+    CTSI_CHECK_ARG(groups > 0 && c % groups == 0, "ctsi_attn_normsum: bad groups");
+    const long long total = (long long)n * h * w * c;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(attn_normsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, depthsum,
+                       sums, gamma, beta, (bf16_t*)out, c, d, (long long)h * w, groups, eps, total);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// y[n][d][pos][ch] = x + p[n][pos][ch] * (rowsum ? rowsum[n][d][pos][head(ch)] : 1)
+__global__ void __launch_bounds__(256)
+attn_broadcast_add_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ pterm,
+                          const float* __restrict__ rowsum, int heads, bf16_t* __restrict__ y, int c, int d,
+                          long long hw, long long total_chunks) {
+    const int cpr = c >> 3;
+    const int hd = c / (heads > 0 ? heads : 1);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total_chunks;
+         e += (long long)gridDim.x * 256) {
+        const int q = (int)(e % cpr);
+        const long long vox = e / cpr;       // (n*d + dd)*hw + pos
+        const long long pos = vox % hw;
+        const long long nd = vox / hw;
+        const long long nb = nd / d;
+        float f[8], pv[8];
+        unpack8a(*reinterpret_cast<const uint4*>(x + e * 8), f);
+        unpack8a(*reinterpret_cast<const uint4*>(pterm + ((nb * hw + pos) * c + q * 8)), pv);
+        float scale = 1.0f;
+        if (rowsum) scale = rowsum[vox * heads + (q * 8) / hd];
+        uint4 o;
+        o.x = pack_bf16x2(f[0] + pv[0] * scale, f[1] + pv[1] * scale);
+        o.y = pack_bf16x2(f[2] + pv[2] * scale, f[3] + pv[3] * scale);
+        o.z = pack_bf16x2(f[4] + pv[4] * scale, f[5] + pv[5] * scale);
+        o.w = pack_bf16x2(f[6] + pv[6] * scale, f[7] + pv[7] * scale);
+        *reinterpret_cast<uint4*>(y + e * 8) = o;
+    }
+}
+
+extern "C" int ctsi_attn_broadcast_add(const void* x, const void* p, const float* rowsum, int heads, void* y,
+                                       int n, int c, int d, int h, int w, void* stream) {
+    CTSI_CHECK_ARG(x && p && y, "ctsi_attn_broadcast_add: null argument");
+    CTSI_CHECK_ARG(c % 8 == 0, "ctsi_attn_broadcast_add: c=%d must be a multiple of 8", c);
+    if (rowsum) CTSI_CHECK_ARG(heads > 0 && c % heads == 0 && (c / heads) % 8 == 0,
+                               "ctsi_attn_broadcast_add: exact mode needs head_dim %% 8 == 0");
+    const long long total = (long long)n * d * h * w * (c / 8);
+    long long blocks = (total + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(attn_broadcast_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)p, rowsum, heads, (bf16_t*)y, c, d, (long long)h * w,
+                       total);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// Exact-mode helper.  qk: bf16 NDHWC with 2c channels (q = first c, k = next c, heads split inside
+// each, models/unet3d.py:171-177).  One wave per (sample, position, head); lane = query index
+// (depth <= 64 per pass), keys looped; fp32 throughout.
+__global__ void __launch_bounds__(256)
+attn_softmax_rowsum_kernel(const bf16_t* __restrict__ qk, float* __restrict__ rowsum, int c, int d,
+                           long long hw, int heads, long long total_items) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= total_items) return;
+    const int head = (int)(item % heads);
+    const long long np = item / heads;   // n*hw + pos
+    const long long pos = np % hw, nb = np / hw;
+    const int hd = c / heads;
+    const float scale = rsqrtf((float)hd);
+    const int c2 = 2 * c;
+    for (int q0 = 0; q0 < d; q0 += 64) {
+        const int qi = q0 + lane;
+        const bool act = qi < d;
+        const bf16_t* qp = qk + (((nb * d + (act ? qi : 0)) * hw + pos) * c2 + head * hd);
+        // pass 1: max, pass 2: sum exp, pass 3 is implicit (rowsum = sum exp / sum exp evaluated
+        // the way softmax does: e_k / denom summed over k)
+        float mx = -3.0e38f;
+        for (int kk = 0; kk < d; ++kk) {
+            const bf16_t* kp = qk + (((nb * d + kk) * hw + pos) * c2 + c + head * hd);
+            float dot = 0.0f;
+            for (int ch = 0; ch < hd; ++ch) dot += bf16_to_f32(qp[ch]) * bf16_to_f32(kp[ch]);
+            mx = fmaxf(mx, dot * scale);
+        }
+        float den = 0.0f;
+        for (int kk = 0; kk < d; ++kk) {
+            const bf16_t* kp = qk + (((nb * d + kk) * hw + pos) * c2 + c + head * hd);
+            float dot = 0.0f;
+            for (int ch = 0; ch < hd; ++ch) dot += bf16_to_f32(qp[ch]) * bf16_to_f32(kp[ch]);
+            den += expf(dot * scale - mx);
+        }
+        float rs = 0.0f;
+        for (int kk = 0; kk < d; ++kk) {
+            const bf16_t* kp = qk + (((nb * d + kk) * hw + pos) * c2 + c + head * hd);
+            float dot = 0.0f;
+            for (int ch = 0; ch < hd; ++ch) dot += bf16_to_f32(qp[ch]) * bf16_to_f32(kp[ch]);
+            rs += expf(dot * scale - mx) / den;
+        }
+        if (act) rowsum[((nb * d + qi) * hw + pos) * heads + head] = rs;
+    }
+}
+
+extern "C" int ctsi_attn_softmax_rowsum(const void* qk, float* rowsum, int n, int c, int d, int h, int w,
+                                        int heads, void* stream) {
+    CTSI_CHECK_ARG(qk && rowsum, "ctsi_attn_softmax_rowsum: null argument");
+    CTSI_CHECK_ARG(heads > 0 && c % heads == 0, "ctsi_attn_softmax_rowsum: c=%d not divisible by heads=%d", c, heads);
+    const long long items = (long long)n * h * w * heads;
+    const long long blocks = (items + 3) / 4;
+    hipLaunchKernelGGL(attn_softmax_rowsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)qk, rowsum, c, d, (long long)h * w, heads, items);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}

@@ -1,0 +1,628 @@
+// Gather-GEMM convolution for gfx950 (MI355X): Conv3d / ConvTranspose3d as an implicit GEMM
+//   rows  M = output voxels of one (TD x TH x TW) tile,
+//   cols  N = output channels,
+//   K     = taps x input channels, walked as 64-wide K-steps,
+// bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+//
+// Replaces (reference): nn.Conv3d / nn.ConvTranspose3d call sites models/unet3d.py:56,96,102,152,
+// 153,204-207,218-221,257,331 and models/vae.py:27,45,65-68,86-89,134,137,161,188.
+//
+// No im2col buffer exists anywhere: each K-step stages a [BM rows][64 ch] slab of the NDHWC
+// input straight from global memory into LDS with global_load_lds (16 B per lane, the per-lane
+// SOURCE address does the tap shift, the stride and the zero padding -> out-of-range taps read
+// a zero page), plus the matching [BN couts][64] slab of the pre-packed weights.  Both slabs use
+// the same XOR swizzle (16-B chunk ^= (row>>1)&7) applied on the source side of the DMA and on
+// the ds_read_b128 fragment reads, which makes the 32x32x16 operand reads conflict-free.
+// Two LDS stages: the DMA of step s+1 is in flight while step s is on the matrix cores.
+//
+// Epilogue: + bias, optional tanh, bf16 tile transposed through LDS for full-line 16-B stores
+// (or strided fp32 stores for the few-channel output layers), and per-tile column sums
+// (sum, sum of squares) for the GroupNorm that follows every large conv on this path.
+#include "ctsi_internal.h"
+#include <string.h>
+#include <stdlib.h>
+#include <math.h>
+
+#define CTSI_MAX_TAPS 48
+#define CTSI_BK 64
+
+__device__ __attribute__((aligned(256))) uint32_t g_ctsi_zero_page[64];  // 256 B of zeros
+
+struct ConvKParams {
+    const bf16_t* x1;
+    const bf16_t* x2;
+    const bf16_t* w;
+    const float* bias;
+    void* y;
+    float* colsum;
+    int C1, C2, Cin;
+    int Di, Hi, Wi;
+    int Dr, Hr, Wr;
+    int sH, sW;
+    int lTH, lTW;
+    int tilesD, tilesH, tilesW, tps, mtiles;
+    int ntiles_n;
+    int T, ksteps, kc_per_tap, lcpt;  // kc_per_tap: 64-chunks per tap (big mode); lcpt: log2(chunks per tap) small
+    int Cout, CoutPad, Ktot;
+    int Do, Ho, Wo, uH, uW;
+    int nclass;
+    int out_mode, cout_stride, c_off, act;
+    long long osn, osc, osd, osh, osw;
+    int tapdelta[CTSI_MAX_TAPS];
+    int8_t od[CTSI_MAX_TAPS], oh[CTSI_MAX_TAPS], ow[CTSI_MAX_TAPS];
+    int8_t pH[4], pW[4];
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+
+// bijective XCD-aware remap of a 1-D block id: blocks that share an XCD get a contiguous range
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + (orig >> 3);
+}
+
+template <int WM, int WN, int TM, int TN, bool SMALL>
+__global__ void __launch_bounds__(WM* WN * 64)
+conv_gather_mfma_kernel(const ConvKParams p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN, NTH = NW * 64;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+    static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
+    static_assert(BM * BN * 2 + NW * 32 * TN * 2 * 4 <= 2 * STAGE, "epilogue tile must fit the stages");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long* s_rowoff = reinterpret_cast<long long*>(smem + 2 * STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- block decode ---------------------------------------------------------------------
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_class = p.mtiles * p.ntiles_n;
+    const int cls = bid / per_class;
+    const int rem = bid - cls * per_class;
+    const int mt = rem / p.ntiles_n;
+    const int nt = rem - mt * p.ntiles_n;
+    const int n0 = nt * BN;
+    const int nb = mt / p.tps;
+    int r0 = mt - nb * p.tps;
+    const int tD = r0 / (p.tilesH * p.tilesW);
+    r0 -= tD * p.tilesH * p.tilesW;
+    const int tH = r0 / p.tilesW;
+    const int tW = r0 - tH * p.tilesW;
+    const int TWm = (1 << p.lTW) - 1, THm = (1 << p.lTH) - 1;
+    const int lTHW = p.lTH + p.lTW;
+    const int d0 = tD * (BM >> lTHW), h0 = tH << p.lTH, w0 = tW << p.lTW;
+    const int tapbase = cls * p.T;
+
+    // ---- per-row bookkeeping ----------------------------------------------------------------
+    if (tid < BM) {
+        const int r = tid;
+        const int d = d0 + (r >> lTHW), h = h0 + ((r >> p.lTW) & THm), w = w0 + (r & TWm);
+        long long off = -1;
+        if (d < p.Dr && h < p.Hr && w < p.Wr) {
+            const int ho = h * p.uH + p.pH[cls], wo = w * p.uW + p.pW[cls];
+            if (p.out_mode == 0)
+                off = ((((long long)nb * p.Do + d) * p.Ho + ho) * p.Wo + wo) * p.cout_stride + p.c_off;
+            else
+                off = (long long)nb * p.osn + (long long)d * p.osd + (long long)ho * p.osh +
+                      (long long)wo * p.osw;
+        }
+        s_rowoff[r] = off;
+    }
+
+    // rows this lane feeds with DMA: instruction j = wave*A_INSTR + i covers rows 8j..8j+7
+    int a_iv0[A_INSTR];
+    unsigned long long a_mask[A_INSTR];
+    int a_q8[A_INSTR];  // logical 16-B chunk (x8 channels) this lane fetches for LDS slot lane&7
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int j = wave * A_INSTR + i;
+        const int r = j * 8 + (lane >> 3);
+        a_q8[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        const int d = d0 + (r >> lTHW), h = h0 + ((r >> p.lTW) & THm), w = w0 + (r & TWm);
+        const bool rv = (d < p.Dr) && (h < p.Hr) && (w < p.Wr);
+        const int hi = h * p.sH, wi = w * p.sW;
+        a_iv0[i] = ((nb * p.Di + d) * p.Hi + hi) * p.Wi + wi;
+        unsigned long long m = 0;
+        for (int t = 0; t < p.T; ++t) {
+            const int dd = d + p.od[tapbase + t], hh = hi + p.oh[tapbase + t], ww = wi + p.ow[tapbase + t];
+            const bool ok = rv && dd >= 0 && dd < p.Di && hh >= 0 && hh < p.Hi && ww >= 0 && ww < p.Wi;
+            m |= (unsigned long long)ok << t;
+        }
+        a_mask[i] = m;
+    }
+    // weight rows this lane feeds
+    const bf16_t* b_ptr[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int j = wave * B_INSTR + i;
+        const int r = j * 8 + (lane >> 3);
+        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        b_ptr[i] = p.w + ((long long)(cls * p.CoutPad + n0 + r)) * p.Ktot + q * 8;
+    }
+    __syncthreads();  // s_rowoff visible
+
+    // All sources are addressed relative to x1 with 64-bit byte offsets so that the per-lane
+    // select between source 1, source 2 and the zero page is plain arithmetic (no pointer loads).
+    const char* x1c = reinterpret_cast<const char*>(p.x1);
+    const long long x2delta = reinterpret_cast<const char*>(p.x2) - x1c;
+    const long long zdelta = reinterpret_cast<const char*>(g_ctsi_zero_page) - x1c;
+    const int C1 = p.C1, C2 = p.C2, Cin = p.Cin, T = p.T, lcpt = p.lcpt;
+    int st_tap = 0, st_cc = 0;  // staging cursor (big mode): tap fastest, then 64-channel chunk
+    // small mode looks tap deltas up per lane: keep the table spread over the wave's lanes and
+    // fetch with a lane permute (no LDS memory access, so it never orders against the DMA).
+    const int td_tab = (lane < T) ? p.tapdelta[tapbase + lane] : 0;
+
+    auto stage = [&](int s, char* buf) {
+        char* a_dst = buf + wave * (A_INSTR * 1024);
+        int td_u = 0;
+        if (!SMALL) td_u = p.tapdelta[tapbase + st_tap];
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            int tap, ch, td;
+            if (SMALL) {
+                const int g = s * 8 + (a_q8[i] >> 3);
+                tap = g >> lcpt;
+                ch = (g & ((1 << lcpt) - 1)) << 3;
+                td = __shfl(td_tab, tap < T ? tap : 0);
+            } else {
+                tap = st_tap;
+                ch = st_cc * 64 + a_q8[i];
+                td = td_u;
+            }
+            const bool ok = (tap < T) & (ch < Cin) & (((a_mask[i] >> tap) & 1ull) != 0ull);
+            const bool second = ch >= C1;
+            const int C = second ? C2 : C1;
+            const int chs = second ? ch - C1 : ch;
+            long long boff = (((long long)a_iv0[i] + td) * C + chs) * 2 + (second ? x2delta : 0ll);
+            boff = ok ? boff : zdelta;
+            glds16(x1c + boff, a_dst + i * 1024);
+        }
+        char* b_dst = buf + A_BYTES + wave * (B_INSTR * 1024);
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            glds16(b_ptr[i], b_dst + i * 1024);
+            b_ptr[i] += CTSI_BK;
+        }
+        if (!SMALL) {
+            if (++st_tap == p.T) {
+                st_tap = 0;
+                ++st_cc;
+            }
+        }
+    };
+
+    // ---- accumulators -------------------------------------------------------------------------
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment read offsets: row = tile_base + (lane&31); (row>>1)&7 == (lane>>1)&7 for 32-aligned bases
+    const int fsw = (lane >> 1) & 7;
+    const int frow = (lane & 31) * 128;
+    int koff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = (((kk * 2 + (lane >> 5)) ^ fsw) << 4) + frow;
+
+    const int S = p.ksteps;
+    stage(0, smem);
+    for (int s = 0; s < S; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        char* cur = smem + (s & 1) * STAGE;
+        if (s + 1 < S) stage(s + 1, smem + ((s + 1) & 1) * STAGE);
+        const char* a_base = cur + (wm * TM * 32) * 128;
+        const char* b_base = cur + A_BYTES + (wn * TN * 32) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(a_base + i * 32 * 128 + koff[kk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(b_base + j * 32 * 128 + koff[kk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // every wave is done with the stage buffers
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);                          // [BM][BN]
+    float* s_cs = reinterpret_cast<float*>(smem + BM * BN * 2);                // [WM][BN][2]
+    const int lhi = lane >> 5, lcol = lane & 31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * TN * 32 + j * 32 + lcol;
+        const int co = n0 + col;
+        const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const long long off = s_rowoff[row];
+                float v = acc[i][j][r] + bv;
+                if (p.act == 1) v = tanhf(v);
+                if (off >= 0) {
+                    s1 += v;
+                    s2 += v * v;
+                }
+                if (p.out_mode == 0) {
+                    s_tile[row * BN + col] = f32_to_bf16(v);
+                } else if (off >= 0 && co < p.Cout) {
+                    reinterpret_cast<float*>(p.y)[off + (long long)co * p.osc] = v;
+                }
+            }
+        }
+        if (p.colsum != nullptr) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lhi == 0) {
+                s_cs[(wm * BN + col) * 2 + 0] = s1;
+                s_cs[(wm * BN + col) * 2 + 1] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    if (p.colsum != nullptr && tid < BN) {
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            t1 += s_cs[(m * BN + tid) * 2 + 0];
+            t2 += s_cs[(m * BN + tid) * 2 + 1];
+        }
+        const long long tg = (long long)cls * p.mtiles + mt;
+        const long long slab = (long long)p.nclass * p.mtiles * p.CoutPad;
+        p.colsum[tg * p.CoutPad + n0 + tid] = t1;
+        p.colsum[slab + tg * p.CoutPad + n0 + tid] = t2;
+    }
+    if (p.out_mode == 0) {
+        constexpr int CPR = BN / 8;  // 16-B chunks per row
+        bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+        for (int c = tid; c < BM * CPR; c += NTH) {
+            const int row = c / CPR, cc = c - row * CPR;
+            const long long off = s_rowoff[row];
+            const int co = n0 + cc * 8;
+            if (off >= 0 && co < p.Cout) {
+                const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + cc * 8);
+                *reinterpret_cast<uint4*>(y + off + co) = v;
+            }
+        }
+    }
+}
+
+// ---- weight packing -----------------------------------------------------------------------------
+struct PackParams {
+    const float* w;
+    bf16_t* out;
+    int nclass, T, Cout, CoutPad, Cin, CinW, Ktot, small, kc_per_tap, lcpt;
+    long long s_co, s_ci;  // element strides of the fp32 weight tensor (tap stride is 1)
+    int tapk[CTSI_MAX_TAPS];
+};
+
+__global__ void conv_pack_weights_kernel(const PackParams q) {
+    const long long total = (long long)q.nclass * q.CoutPad * q.Ktot;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % q.Ktot);
+        const long long rc = idx / q.Ktot;
+        const int co = (int)(rc % q.CoutPad);
+        const int cls = (int)(rc / q.CoutPad);
+        int tap, ci;
+        if (q.small) {
+            const int g = k >> 3;
+            tap = g >> q.lcpt;
+            ci = ((g & ((1 << q.lcpt) - 1)) << 3) + (k & 7);
+        } else {
+            const int s = k >> 6;
+            tap = s % q.T;
+            ci = (s / q.T) * 64 + (k & 63);
+        }
+        float v = 0.0f;
+        if (tap < q.T && ci < q.CinW && co < q.Cout)
+            v = q.w[(long long)co * q.s_co + (long long)ci * q.s_ci + q.tapk[cls * q.T + tap]];
+        q.out[idx] = f32_to_bf16(v);
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------
+struct ctsi_conv_plan {
+    ctsi_conv_desc d;
+    int Cin, CinW;
+    int Do, Ho, Wo;
+    int Dr, Hr, Wr, sH, sW, uH, uW;
+    int nclass, T;
+    int small, lcpt, kc_per_tap, ksteps, Ktot;
+    int BM, BN, CoutPad, ntiles_n;
+    int lTH, lTW, TD, TH, TW, tilesD, tilesH, tilesW, tps, mtiles;
+    int tapk[CTSI_MAX_TAPS];
+    int tapdelta[CTSI_MAX_TAPS];
+    int8_t od[CTSI_MAX_TAPS], oh[CTSI_MAX_TAPS], ow[CTSI_MAX_TAPS];
+    int8_t pH[4], pW[4];
+    double flops;
+};
+
+static int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+// pick the power-of-two (TD,TH,TW) with TD*TH*TW == bm that covers the row grid with the fewest
+// padded rows; ties go to the most cube-like tile (smallest halo for the L2).
+static void choose_tile(int bm, int Dr, int Hr, int Wr, int* TD, int* TH, int* TW) {
+    long long best = -1;
+    int bsurf = 0;
+    const int lb = ilog2(bm);
+    for (int lw = 0; lw <= lb; ++lw)
+        for (int lh = 0; lh + lw <= lb; ++lh) {
+            const int tw = 1 << lw, th = 1 << lh, td = bm >> (lw + lh);
+            const long long tiles = (long long)ceil_div(Dr, td) * ceil_div(Hr, th) * ceil_div(Wr, tw);
+            const int surf = (td + 2) * (th + 2) * (tw + 2);
+            if (best < 0 || tiles < best || (tiles == best && surf < bsurf)) {
+                best = tiles;
+                bsurf = surf;
+                *TD = td;
+                *TH = th;
+                *TW = tw;
+            }
+        }
+}
+
+extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc* desc) {
+    CTSI_CHECK_ARG(out && desc, "ctsi_conv_plan_create: null argument");
+    const ctsi_conv_desc& d = *desc;
+    CTSI_CHECK_ARG(d.n > 0 && d.c1 > 0 && d.c2 >= 0 && d.cout > 0 && d.di > 0 && d.hi > 0 && d.wi > 0,
+                   "ctsi_conv_plan_create: bad sizes n=%d c1=%d c2=%d cout=%d in=%dx%dx%d", d.n, d.c1,
+                   d.c2, d.cout, d.di, d.hi, d.wi);
+    CTSI_CHECK_ARG(d.c1 % 8 == 0 && d.c2 % 8 == 0,
+                   "ctsi_conv_plan_create: source channel counts must be multiples of 8 (got %d, %d); "
+                   "pad the tensor at the layout boundary", d.c1, d.c2);
+    CTSI_CHECK_ARG(d.kd >= 1 && d.kh >= 1 && d.kw >= 1 && d.sh >= 1 && d.sw >= 1,
+                   "ctsi_conv_plan_create: bad kernel/stride");
+    ctsi_conv_plan* p = (ctsi_conv_plan*)calloc(1, sizeof(ctsi_conv_plan));
+    if (!p) {
+        ctsi_set_error("ctsi_conv_plan_create: out of host memory");
+        return CTSI_ERR_INVALID;
+    }
+    p->d = d;
+    p->Cin = d.c1 + d.c2;
+    p->CinW = p->Cin;
+    const int KK = d.kd * d.kh * d.kw;
+    if (!d.transposed) {
+        p->Do = d.di + 2 * d.pd - d.kd + 1;
+        p->Ho = (d.hi + 2 * d.ph - d.kh) / d.sh + 1;
+        p->Wo = (d.wi + 2 * d.pw - d.kw) / d.sw + 1;
+        if (KK > CTSI_MAX_TAPS || p->Do <= 0 || p->Ho <= 0 || p->Wo <= 0) {
+            free(p);
+            ctsi_set_error("ctsi_conv_plan_create: unsupported Conv3d geometry k=(%d,%d,%d)", d.kd, d.kh, d.kw);
+            return CTSI_ERR_UNSUPPORTED;
+        }
+        p->nclass = 1;
+        p->T = KK;
+        p->Dr = p->Do; p->Hr = p->Ho; p->Wr = p->Wo;
+        p->sH = d.sh; p->sW = d.sw; p->uH = 1; p->uW = 1;
+        p->pH[0] = 0; p->pW[0] = 0;
+        int t = 0;
+        for (int a = 0; a < d.kd; ++a)
+            for (int b = 0; b < d.kh; ++b)
+                for (int c = 0; c < d.kw; ++c, ++t) {
+                    p->od[t] = (int8_t)(a - d.pd);
+                    p->oh[t] = (int8_t)(b - d.ph);
+                    p->ow[t] = (int8_t)(c - d.pw);
+                    p->tapk[t] = (a * d.kh + b) * d.kw + c;
+                }
+    } else {
+        // ConvTranspose3d, depth stride 1: o_d = i_d - pd + k_d; o_h = i_h*sh - ph + k_h.
+        // One parity class per (o_h % sh, o_w % sw); each class is a stride-1 gather conv on the
+        // input grid with kd * (kh/sh) * (kw/sw) taps.
+        const bool ok = d.sh == 2 && d.sw == 2 && d.kh == 4 && d.kw == 4 && d.ph == 1 && d.pw == 1 &&
+                        d.kd == 3 && d.pd == 1;
+        if (!ok) {
+            free(p);
+            ctsi_set_error("ctsi_conv_plan_create: ConvTranspose3d supports k=(3,4,4) s=(1,2,2) p=1 only");
+            return CTSI_ERR_UNSUPPORTED;
+        }
+        p->Do = d.di; p->Ho = d.hi * 2; p->Wo = d.wi * 2;
+        p->nclass = 4;
+        p->T = 12;
+        p->Dr = d.di; p->Hr = d.hi; p->Wr = d.wi;
+        p->sH = 1; p->sW = 1; p->uH = 2; p->uW = 2;
+        for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+            p->pH[cls] = (int8_t)py;
+            p->pW[cls] = (int8_t)px;
+            // output o = 2m+py receives (k, i): py=0 -> (1,m),(3,m-1); py=1 -> (2,m),(0,m+1)
+            const int ky[2] = {py == 0 ? 1 : 2, py == 0 ? 3 : 0};
+            const int oy[2] = {0, py == 0 ? -1 : 1};
+            const int kx[2] = {px == 0 ? 1 : 2, px == 0 ? 3 : 0};
+            const int ox[2] = {0, px == 0 ? -1 : 1};
+            int t = cls * 12;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 2; ++b)
+                    for (int c = 0; c < 2; ++c, ++t) {
+                        p->od[t] = (int8_t)(1 - a);  // i_d = o_d + pd - k_d
+                        p->oh[t] = (int8_t)oy[b];
+                        p->ow[t] = (int8_t)ox[c];
+                        p->tapk[t] = (a * 4 + ky[b]) * 4 + kx[c];
+                    }
+        }
+    }
+    for (int t = 0; t < p->nclass * p->T; ++t)
+        p->tapdelta[t] = (p->od[t] * d.hi + p->oh[t]) * d.wi + p->ow[t];
+
+    // K walk
+    if (p->Cin <= 32 && (p->Cin & (p->Cin - 1)) == 0) {
+        p->small = 1;
+        p->lcpt = ilog2(p->Cin / 8);
+        const int chunks = p->T << p->lcpt;
+        p->ksteps = ceil_div(chunks, 8);
+        p->kc_per_tap = 0;
+    } else {
+        p->small = 0;
+        p->kc_per_tap = ceil_div(p->Cin, 64);
+        p->ksteps = p->T * p->kc_per_tap;
+    }
+    p->Ktot = p->ksteps * CTSI_BK;
+    p->BM = 128;
+    p->BN = d.cout <= 32 ? 32 : 128;
+    p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
+    p->ntiles_n = p->CoutPad / p->BN;
+    choose_tile(p->BM, p->Dr, p->Hr, p->Wr, &p->TD, &p->TH, &p->TW);
+    p->lTH = ilog2(p->TH);
+    p->lTW = ilog2(p->TW);
+    p->tilesD = ceil_div(p->Dr, p->TD);
+    p->tilesH = ceil_div(p->Hr, p->TH);
+    p->tilesW = ceil_div(p->Wr, p->TW);
+    p->tps = p->tilesD * p->tilesH * p->tilesW;
+    p->mtiles = d.n * p->tps;
+    if (!d.transposed)
+        p->flops = 2.0 * d.n * (double)p->Do * p->Ho * p->Wo * p->Cin * d.cout * KK;
+    else
+        p->flops = 2.0 * d.n * (double)d.di * d.hi * d.wi * p->Cin * d.cout * KK;
+    *out = p;
+    return CTSI_OK;
+}
+
+extern "C" void ctsi_conv_plan_destroy(ctsi_conv_plan* plan) { free(plan); }
+
+extern "C" int ctsi_conv_plan_out_dims(const ctsi_conv_plan* p, int* d, int* h, int* w) {
+    CTSI_CHECK_ARG(p, "ctsi_conv_plan_out_dims: null plan");
+    if (d) *d = p->Do;
+    if (h) *h = p->Ho;
+    if (w) *w = p->Wo;
+    return CTSI_OK;
+}
+extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
+    return p ? (size_t)p->nclass * p->CoutPad * p->Ktot * 2 : 0;
+}
+extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) { return p ? p->nclass * p->mtiles : 0; }
+extern "C" int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* p) { return p ? p->tps : 0; }
+extern "C" int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* p) { return p ? p->CoutPad : 0; }
+extern "C" double ctsi_conv_plan_flops(const ctsi_conv_plan* p) { return p ? p->flops : 0.0; }
+
+// The weight tensor may carry fewer input channels than the (padded) activation tensor: the
+// VAE encoder's first conv sees a 1-channel volume stored as 8 channels (7 zero).
+extern "C" int ctsi_conv_plan_set_weight_cin(ctsi_conv_plan* p, int cin_w) {
+    CTSI_CHECK_ARG(p && cin_w > 0 && cin_w <= p->Cin, "ctsi_conv_plan_set_weight_cin: bad cin %d", cin_w);
+    p->CinW = cin_w;
+    return CTSI_OK;
+}
+
+extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float* w, void* packed,
+                                           void* stream) {
+    CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
+    PackParams q;
+    memset(&q, 0, sizeof(q));
+    q.w = w;
+    q.out = (bf16_t*)packed;
+    q.nclass = p->nclass;
+    q.T = p->T;
+    q.Cout = p->d.cout;
+    q.CoutPad = p->CoutPad;
+    q.Cin = p->Cin;
+    q.CinW = p->CinW;
+    q.Ktot = p->Ktot;
+    q.small = p->small;
+    q.kc_per_tap = p->kc_per_tap;
+    q.lcpt = p->lcpt;
+    const long long KK = (long long)p->d.kd * p->d.kh * p->d.kw;
+    if (!p->d.transposed) {
+        q.s_co = (long long)p->CinW * KK;
+        q.s_ci = KK;
+    } else {
+        q.s_ci = (long long)p->d.cout * KK;
+        q.s_co = KK;
+    }
+    memcpy(q.tapk, p->tapk, sizeof(q.tapk));
+    const long long total = (long long)q.nclass * q.CoutPad * q.Ktot;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, q);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_conv(const ConvKParams& k, bool small, int grid, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr size_t lds = 2 * (BM * 128 + BN * 128) + BM * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (small)
+        hipLaunchKernelGGL((conv_gather_mfma_kernel<WM, WN, TM, TN, true>), dim3(grid), dim3(WM * WN * 64),
+                           lds, st, k);
+    else
+        hipLaunchKernelGGL((conv_gather_mfma_kernel<WM, WN, TM, TN, false>), dim3(grid), dim3(WM * WN * 64),
+                           lds, st, k);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void* x2, const void* packed_w,
+                             const float* bias, const ctsi_conv_out* o, void* stream) {
+    CTSI_CHECK_ARG(p && x1 && packed_w && o && o->y, "ctsi_conv_fwd: null argument");
+    CTSI_CHECK_ARG(p->d.c2 == 0 || x2 != nullptr, "ctsi_conv_fwd: plan has two sources but x2 is null");
+    CTSI_CHECK_ARG(o->mode == 0 || o->mode == 1, "ctsi_conv_fwd: bad output mode %d", o->mode);
+    if (o->mode == 0) {
+        CTSI_CHECK_ARG(p->d.cout % 8 == 0 && o->cout_stride % 8 == 0 && o->c_off % 8 == 0 &&
+                           o->cout_stride >= o->c_off + p->d.cout,
+                       "ctsi_conv_fwd: bf16 output needs cout, cout_stride, c_off multiples of 8 "
+                       "(cout=%d stride=%d off=%d)", p->d.cout, o->cout_stride, o->c_off);
+    }
+    ConvKParams k;
+    memset(&k, 0, sizeof(k));
+    k.x1 = (const bf16_t*)x1;
+    k.x2 = (const bf16_t*)(x2 ? x2 : x1);
+    k.w = (const bf16_t*)packed_w;
+    k.bias = bias;
+    k.y = o->y;
+    k.colsum = o->colsum;
+    k.C1 = p->d.c1; k.C2 = p->d.c2; k.Cin = p->Cin;
+    k.Di = p->d.di; k.Hi = p->d.hi; k.Wi = p->d.wi;
+    k.Dr = p->Dr; k.Hr = p->Hr; k.Wr = p->Wr;
+    k.sH = p->sH; k.sW = p->sW;
+    k.lTH = p->lTH; k.lTW = p->lTW;
+    k.tilesD = p->tilesD; k.tilesH = p->tilesH; k.tilesW = p->tilesW; k.tps = p->tps; k.mtiles = p->mtiles;
+    k.ntiles_n = p->ntiles_n;
+    k.T = p->T; k.ksteps = p->ksteps; k.kc_per_tap = p->kc_per_tap; k.lcpt = p->lcpt;
+    k.Cout = p->d.cout; k.CoutPad = p->CoutPad; k.Ktot = p->Ktot;
+    k.Do = p->Do; k.Ho = p->Ho; k.Wo = p->Wo; k.uH = p->uH; k.uW = p->uW;
+    k.nclass = p->nclass;
+    k.out_mode = o->mode; k.cout_stride = o->cout_stride; k.c_off = o->c_off; k.act = o->act;
+    k.osn = o->sn; k.osc = o->sc; k.osd = o->sd; k.osh = o->sh; k.osw = o->sw;
+    memcpy(k.tapdelta, p->tapdelta, sizeof(k.tapdelta));
+    memcpy(k.od, p->od, sizeof(k.od));
+    memcpy(k.oh, p->oh, sizeof(k.oh));
+    memcpy(k.ow, p->ow, sizeof(k.ow));
+    memcpy(k.pH, p->pH, sizeof(k.pH));
+    memcpy(k.pW, p->pW, sizeof(k.pW));
+    const int grid = p->nclass * p->mtiles * p->ntiles_n;
+    hipStream_t st = (hipStream_t)stream;
+    if (p->BN == 128) return launch_conv<2, 2, 2, 2>(k, p->small != 0, grid, st);
+    return launch_conv<4, 1, 1, 1>(k, p->small != 0, grid, st);
+}

@@ -1,0 +1,68 @@
+// Internal helpers shared by the HIP translation units of libctsi (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/ctsi.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---- error plumbing -------------------------------------------------------------------------
+void ctsi_set_error(const char* fmt, ...);
+
+#define CTSI_CHECK_ARG(cond, ...)            \
+    do {                                     \
+        if (!(cond)) {                       \
+            ctsi_set_error(__VA_ARGS__);     \
+            return CTSI_ERR_INVALID;         \
+        }                                    \
+    } while (0)
+
+#define CTSI_HIP(call)                                                                  \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            ctsi_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),       \
+                           __FILE__, __LINE__);                                         \
+            return CTSI_ERR_HIP;                                                        \
+        }                                                                               \
+    } while (0)
+
+#define CTSI_LAUNCH_CHECK()                                                             \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            ctsi_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_),   \
+                           __FILE__, __LINE__);                                         \
+            return CTSI_ERR_HIP;                                                        \
+        }                                                                               \
+    } while (0)
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even; a plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float nan_to_num_f(float v) {
+    // torch.nan_to_num(v, nan=0.0, posinf=1.0, neginf=-1.0)
+    if (v != v) return 0.0f;
+    if (v == __builtin_inff()) return 1.0f;
+    if (v == -__builtin_inff()) return -1.0f;
+    return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

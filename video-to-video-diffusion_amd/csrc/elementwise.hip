@@ -1,0 +1,313 @@
+// Boundary layout conversions, trilinear depth upsample, timestep embedding and the DDIM / DDPM
+// elementwise updates (all HBM- or latency-bound; vectorised 16-B accesses where the layout allows).
+// Reference semantics: models/model.py:252-343 (fp32 NCDHW API tensors, nan_to_num guards,
+// F.interpolate trilinear), models/unet3d.py:18-48,88-91,123-125 (time embedding),
+// inference/sampler.py:294-334 (DDIM update), models/diffusion.py:270-338 (DDPM update).
+#include "ctsi_internal.h"
+#include <math.h>
+
+// ---- fp32 NCDHW -> bf16 NDHWC channel slice -------------------------------------------------------
+__global__ void __launch_bounds__(256)
+ncdhw_f32_to_ndhwc_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int c, long long vox,
+                               int c_total, int c_off, long long total /* n*vox */) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long nb = e / vox, v = e - nb * vox;
+        const float* s = src + nb * c * vox + v;
+        bf16_t* o = dst + e * c_total + c_off;
+        int ch = 0;
+        if (((c_total | c_off) & 7) == 0) {
+            for (; ch + 8 <= c; ch += 8) {
+                uint4 pk;
+                pk.x = pack_bf16x2(s[(ch + 0) * vox], s[(ch + 1) * vox]);
+                pk.y = pack_bf16x2(s[(ch + 2) * vox], s[(ch + 3) * vox]);
+                pk.z = pack_bf16x2(s[(ch + 4) * vox], s[(ch + 5) * vox]);
+                pk.w = pack_bf16x2(s[(ch + 6) * vox], s[(ch + 7) * vox]);
+                *reinterpret_cast<uint4*>(o + ch) = pk;
+            }
+        }
+        for (; ch < c; ++ch) o[ch] = f32_to_bf16(s[ch * vox]);
+    }
+}
+
+extern "C" int ctsi_ncdhw_f32_to_ndhwc_bf16(const float* src, void* dst, int n, int c, int d, int h, int w,
+                                            int c_total, int c_off, void* stream) {
+    CTSI_CHECK_ARG(src && dst && n > 0 && c > 0 && c_off >= 0 && c_off + c <= c_total,
+                   "ctsi_ncdhw_f32_to_ndhwc_bf16: bad arguments (c=%d c_total=%d c_off=%d)", c, c_total, c_off);
+    const long long vox = (long long)d * h * w, total = vox * n;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(ncdhw_f32_to_ndhwc_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       src, (bf16_t*)dst, c, vox, c_total, c_off, total);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// ---- bf16 NDHWC -> fp32 NCDHW ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+ndhwc_bf16_to_ncdhw_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int c, long long vox,
+                               long long total) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long nb = e / vox, v = e - nb * vox;
+        const bf16_t* s = src + e * c;
+        float* o = dst + nb * c * vox + v;
+        for (int ch = 0; ch < c; ++ch) o[ch * vox] = bf16_to_f32(s[ch]);
+    }
+}
+
+extern "C" int ctsi_ndhwc_bf16_to_ncdhw_f32(const void* src, float* dst, int n, int c, int d, int h, int w,
+                                            void* stream) {
+    CTSI_CHECK_ARG(src && dst && n > 0 && c > 0, "ctsi_ndhwc_bf16_to_ncdhw_f32: bad arguments");
+    const long long vox = (long long)d * h * w, total = vox * n;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(ndhwc_bf16_to_ncdhw_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, dst, c, vox, total);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// ---- fp32 NCDHW <-> fp32 NDHWC ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+f32_layout_kernel(const float* __restrict__ src, float* __restrict__ dst, int c, long long vox, long long total,
+                  int to_ndhwc) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long nb = e / vox, v = e - nb * vox;
+        if (to_ndhwc) {
+            for (int ch = 0; ch < c; ++ch) dst[e * c + ch] = src[(nb * c + ch) * vox + v];
+        } else {
+            for (int ch = 0; ch < c; ++ch) dst[(nb * c + ch) * vox + v] = src[e * c + ch];
+        }
+    }
+}
+static int f32_layout(const float* src, float* dst, int n, int c, int d, int h, int w, int to_ndhwc, void* stream) {
+    CTSI_CHECK_ARG(src && dst && n > 0 && c > 0, "fp32 layout conversion: bad arguments");
+    const long long vox = (long long)d * h * w, total = vox * n;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(f32_layout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, c,
+                       vox, total, to_ndhwc);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+extern "C" int ctsi_ncdhw_f32_to_ndhwc_f32(const float* src, float* dst, int n, int c, int d, int h, int w,
+                                           void* stream) {
+    return f32_layout(src, dst, n, c, d, h, w, 1, stream);
+}
+extern "C" int ctsi_ndhwc_f32_to_ncdhw_f32(const float* src, float* dst, int n, int c, int d, int h, int w,
+                                           void* stream) {
+    return f32_layout(src, dst, n, c, d, h, w, 0, stream);
+}
+
+// ---- trilinear depth upsample (h, w unchanged) ---------------------------------------------------------------
+// src index (align_corners=False): s = max((d + 0.5) * d_in/d_out - 0.5, 0); i0 = floor(s);
+// i1 = min(i0 + 1, d_in - 1); out = (1 - (s - i0)) * x[i0] + (s - i0) * x[i1]    (fp32)
+__global__ void __launch_bounds__(256)
+trilinear_depth_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst_bf16, float* __restrict__ dst_f32,
+                       int c, int d_in, int d_out, long long hw, int c_total, int c_off, long long total) {
+    const float scale = (float)d_in / (float)d_out;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long p = e % hw;
+        const long long nd = e / hw;
+        const int dd = (int)(nd % d_out);
+        const long long nb = nd / d_out;
+        float s = scale * ((float)dd + 0.5f) - 0.5f;
+        if (s < 0.0f) s = 0.0f;
+        const int i0 = (int)s;
+        const int i1 = i0 + (i0 < d_in - 1 ? 1 : 0);
+        const float l1 = s - (float)i0, l0 = 1.0f - l1;
+        for (int ch = 0; ch < c; ++ch) {
+            const float* sp = src + ((nb * c + ch) * d_in) * hw + p;
+            const float v = l0 * sp[(long long)i0 * hw] + l1 * sp[(long long)i1 * hw];
+            if (dst_bf16) dst_bf16[e * c_total + c_off + ch] = f32_to_bf16(v);
+            if (dst_f32) dst_f32[((nb * c + ch) * d_out + dd) * hw + p] = v;
+        }
+    }
+}
+
+extern "C" int ctsi_trilinear_depth_fwd(const float* src, void* dst_bf16, int n, int c, int d_in, int d_out,
+                                        int h, int w, int c_total, int c_off, float* dst_f32, void* stream) {
+    CTSI_CHECK_ARG(src && (dst_bf16 || dst_f32) && d_in > 0 && d_out > 0, "ctsi_trilinear_depth_fwd: bad arguments");
+    CTSI_CHECK_ARG(!dst_bf16 || (c_off >= 0 && c_off + c <= c_total), "ctsi_trilinear_depth_fwd: bad channel slice");
+    const long long hw = (long long)h * w, total = (long long)n * d_out * hw;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(trilinear_depth_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst_bf16, dst_f32, c, d_in, d_out, hw, c_total, c_off, total);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// ---- timestep embedding ---------------------------------------------------------------------------------------------
+// rows = (steps x batch) timestep values.  Three launches:
+//   (1) sincos + Linear1 + SiLU   (2) Linear2   (3) all per-ResBlock Linear(SiLU(temb)) stacked.
+// One wave per output feature; the wave keeps its weight row in registers and walks the rows.
+__global__ void __launch_bounds__(256)
+time_sincos_kernel(const int* __restrict__ t_rows, int rows, int dim, float* __restrict__ out) {
+    const int half = dim / 2;
+    const float step = logf(10000.0f) / (float)(half - 1);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < rows * half; e += gridDim.x * 256) {
+        const int r = e / half, i = e - r * half;
+        const float freq = expf((float)i * -step);
+        const float arg = (float)t_rows[r] * freq;
+        out[r * dim + i] = sinf(arg);
+        out[r * dim + half + i] = cosf(arg);
+    }
+}
+
+// out[r][o] = act_out( W[o] . act_in(in[r]) + b[o] );  in_dim <= 2048
+__global__ void __launch_bounds__(256)
+time_linear_kernel(const float* __restrict__ in, int rows, int in_dim, const float* __restrict__ w,
+                   const float* __restrict__ b, int out_dim, float* __restrict__ out, int silu_in, int silu_out) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= out_dim) return;
+    constexpr int MAXK = 32;  // in_dim <= 64*32
+    float wr[MAXK];
+    const int nk = (in_dim + 63) / 64;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int idx = k * 64 + lane;
+        wr[k] = (k < nk && idx < in_dim) ? w[(long long)o * in_dim + idx] : 0.0f;
+    }
+    const float bias = b[o];
+    for (int r = 0; r < rows; ++r) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            const int idx = k * 64 + lane;
+            if (k < nk && idx < in_dim) {
+                float v = in[(long long)r * in_dim + idx];
+                if (silu_in) v = silu_f(v);
+                acc += wr[k] * v;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) {
+            float v = acc + bias;
+            if (silu_out) v = silu_f(v);
+            out[(long long)r * out_dim + o] = v;
+        }
+    }
+}
+
+extern "C" int ctsi_time_embed_fwd(const int* t_rows, int rows, int dim, int time_dim, const float* w1,
+                                   const float* b1, const float* w2, const float* b2, const float* w_all,
+                                   const float* b_all, int total_out, float* scratch, float* tbias_out,
+                                   void* stream) {
+    CTSI_CHECK_ARG(t_rows && w1 && b1 && w2 && b2 && scratch, "ctsi_time_embed_fwd: null argument");
+    CTSI_CHECK_ARG(rows > 0 && dim >= 4 && dim % 2 == 0 && dim <= 2048 && time_dim > 0 && time_dim <= 2048,
+                   "ctsi_time_embed_fwd: unsupported sizes dim=%d time_dim=%d", dim, time_dim);
+    hipStream_t st = (hipStream_t)stream;
+    float* sincos = scratch;                           // rows*dim
+    float* hidden = scratch + (long long)rows * dim;   // rows*time_dim
+    float* temb = hidden + (long long)rows * time_dim; // rows*time_dim
+    int blocks = (rows * (dim / 2) + 255) / 256;
+    hipLaunchKernelGGL(time_sincos_kernel, dim3(blocks), dim3(256), 0, st, t_rows, rows, dim, sincos);
+    CTSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(time_linear_kernel, dim3((time_dim + 3) / 4), dim3(256), 0, st, sincos, rows, dim, w1, b1,
+                       time_dim, hidden, 0, 1);
+    CTSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(time_linear_kernel, dim3((time_dim + 3) / 4), dim3(256), 0, st, hidden, rows, time_dim, w2,
+                       b2, time_dim, temb, 0, 0);
+    CTSI_LAUNCH_CHECK();
+    if (total_out > 0) {
+        CTSI_CHECK_ARG(w_all && b_all && tbias_out, "ctsi_time_embed_fwd: null stacked projection");
+        hipLaunchKernelGGL(time_linear_kernel, dim3((total_out + 3) / 4), dim3(256), 0, st, temb, rows, time_dim,
+                           w_all, b_all, total_out, tbias_out, 1, 0);
+        CTSI_LAUNCH_CHECK();
+    }
+    return CTSI_OK;
+}
+
+// ---- sampler updates ---------------------------------------------------------------------------------------------------
+// coef row layout (8 floats), built on the host with fp32 torch ops exactly as the reference does:
+//  DDIM: [0]=sqrt(1-a_t+1e-8) [1]=sqrt(a_t+1e-8)+1e-8 [2]=sqrt(a_prev+1e-8) [3]=sqrt(1-a_prev+1e-8) [4]=sigma_t
+//  DDPM: [0]=sqrt(1-abar_t)   [1]=sqrt(abar_t)        [2]=post_mean_coef1   [3]=post_mean_coef2     [4]=(t!=0)*exp(0.5*logvar)
+// z, eps: fp32 NDHWC.  noise: fp32 NCDHW (the layout torch.randn_like(z) has in the reference) or NULL.
+template <bool DDPM>
+__global__ void __launch_bounds__(256)
+sampler_step_kernel(float* __restrict__ z, const float* __restrict__ eps, const float* __restrict__ noise,
+                    bf16_t* __restrict__ zin, int c_total, int c_off, const float* __restrict__ coef,
+                    const int* __restrict__ step_ptr, int c, long long vox, long long total) {
+    const float* cf = coef + (long long)(step_ptr ? *step_ptr : 0) * 8;
+    const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4];
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int ch = (int)(e % c);
+        const long long nv = e / c;  // n*vox + v
+        float ep = eps[e];
+        const float zt = z[e];
+        float zn;
+        if (DDPM) {
+            float z0 = (zt - c0 * ep) / c1;
+            z0 = fminf(fmaxf(z0, -1.0f), 1.0f);
+            zn = c2 * z0 + c3 * zt;
+            if (noise) {
+                const long long nb = nv / vox, v = nv - nb * vox;
+                zn += c4 * noise[(nb * c + ch) * vox + v];
+            }
+        } else {
+            ep = nan_to_num_f(ep);
+            float z0 = (zt - c0 * ep) / c1;
+            z0 = nan_to_num_f(z0);
+            z0 = fminf(fmaxf(z0, -10.0f), 10.0f);
+            zn = c2 * z0 + c3 * ep;
+            if (noise) {
+                const long long nb = nv / vox, v = nv - nb * vox;
+                zn += c4 * noise[(nb * c + ch) * vox + v];
+            }
+            zn = nan_to_num_f(zn);
+        }
+        z[e] = zn;
+        if (zin) zin[nv * c_total + c_off + ch] = f32_to_bf16(zn);
+    }
+}
+
+template <bool DDPM>
+static int sampler_step(float* z, const float* eps, const float* noise, void* zin, int c_total, int c_off,
+                        const float* coef, const int* step_ptr, int n, int c, int d, int h, int w, void* stream) {
+    CTSI_CHECK_ARG(z && eps && coef, "sampler step: null argument");
+    CTSI_CHECK_ARG(!zin || (c_off >= 0 && c_off + c <= c_total), "sampler step: bad channel slice");
+    const long long vox = (long long)d * h * w, total = vox * n * c;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((sampler_step_kernel<DDPM>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z,
+                       eps, noise, (bf16_t*)zin, c_total, c_off, coef, step_ptr, c, vox, total);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+extern "C" int ctsi_ddim_step(float* z, const float* eps, const float* noise, void* zin, int c_total, int c_off,
+                              const float* coef, const int* step_ptr, int n, int c, int d, int h, int w,
+                              void* stream) {
+    return sampler_step<false>(z, eps, noise, zin, c_total, c_off, coef, step_ptr, n, c, d, h, w, stream);
+}
+extern "C" int ctsi_ddpm_step(float* z, const float* eps, const float* noise, void* zin, int c_total, int c_off,
+                              const float* coef, const int* step_ptr, int n, int c, int d, int h, int w,
+                              void* stream) {
+    return sampler_step<true>(z, eps, noise, zin, c_total, c_off, coef, step_ptr, n, c, d, h, w, stream);
+}
+
+__global__ void step_advance_kernel(int* step_ptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr += 1;
+}
+extern "C" int ctsi_step_advance(int* step_ptr, void* stream) {
+    CTSI_CHECK_ARG(step_ptr, "ctsi_step_advance: null argument");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_ptr);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+__global__ void __launch_bounds__(256) nan_to_num_kernel(float* x, long long count) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256)
+        x[e] = nan_to_num_f(x[e]);
+}
+extern "C" int ctsi_nan_to_num_f32(float* x, long long count, void* stream) {
+    CTSI_CHECK_ARG(x && count >= 0, "ctsi_nan_to_num_f32: bad arguments");
+    if (count == 0) return CTSI_OK;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nan_to_num_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, count);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}

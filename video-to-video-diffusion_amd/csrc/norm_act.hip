@@ -1,0 +1,217 @@
+// GroupNorm statistics + fused normalise / SiLU / time-bias / residual kernels (HBM-bound).
+// Replaces nn.GroupNorm + nn.SiLU + the ResBlock tails of the reference:
+//   models/unet3d.py:59-60,70-74,95-98,116-133,151,167,328-330 and models/vae.py:28-35,44-56,69-76,90-97.
+// All tensors are bf16 NDHWC; every global access is a 16-byte (8-channel) vector per lane.
+// Statistics path: per-tile column sums (conv epilogue or gn_colsum_kernel) -> gn_finalize_kernel
+// (fp64 (sum, sumsq) per (sample, group)) -> gn_apply_kernel.
+#include "ctsi_internal.h"
+
+#define GN_TILE_ROWS 512
+
+__device__ __forceinline__ void unpack8(const uint4 v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+
+// ---- column sums of a tensor no conv produced ------------------------------------------------
+// grid: (tiles_per_sample, n); block 256.  cpr = c/8 16-byte chunks per voxel.
+__global__ void __launch_bounds__(256)
+gn_colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ colsum, int n_total, int c,
+                 long long vox_per_sample, int tps) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_red = reinterpret_cast<float*>(smem_raw);  // [rows_par][c][2]
+    const int cpr = c >> 3;
+    const int rows_par = 256 / cpr;
+    const int tid = threadIdx.x;
+    const int q = tid % cpr, rl = tid / cpr;
+    const int tile = blockIdx.x, nb = blockIdx.y;
+    const long long v0 = (long long)tile * GN_TILE_ROWS;
+    long long v1 = v0 + GN_TILE_ROWS;
+    if (v1 > vox_per_sample) v1 = vox_per_sample;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.0f;
+    if (rl < rows_par) {
+        const bf16_t* base = x + ((long long)nb * vox_per_sample) * c + q * 8;
+        for (long long v = v0 + rl; v < v1; v += rows_par) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(base + v * c);
+            float f[8];
+            unpack8(raw, f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                s1[k] += f[k];
+                s2[k] += f[k] * f[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s_red[((rl * c) + q * 8 + k) * 2 + 0] = s1[k];
+            s_red[((rl * c) + q * 8 + k) * 2 + 1] = s2[k];
+        }
+    }
+    __syncthreads();
+    for (int col = tid; col < c; col += 256) {
+        float t1 = 0.0f, t2 = 0.0f;
+        for (int r = 0; r < rows_par; ++r) {
+            t1 += s_red[(r * c + col) * 2 + 0];
+            t2 += s_red[(r * c + col) * 2 + 1];
+        }
+        const long long tg = (long long)nb * tps + tile;
+        const long long slab = (long long)n_total * tps * c;
+        colsum[tg * c + col] = t1;
+        colsum[slab + tg * c + col] = t2;
+    }
+}
+
+extern "C" int ctsi_gn_colsum_tiles(int d, int h, int w) {
+    const long long vox = (long long)d * h * w;
+    return (int)((vox + GN_TILE_ROWS - 1) / GN_TILE_ROWS);
+}
+
+extern "C" int ctsi_gn_colsum(const void* x, float* colsum, int n, int c, int d, int h, int w,
+                              int* tiles_per_sample, void* stream) {
+    CTSI_CHECK_ARG(x && colsum, "ctsi_gn_colsum: null argument");
+    CTSI_CHECK_ARG(c % 8 == 0 && c >= 8 && c <= 2048, "ctsi_gn_colsum: c=%d must be a multiple of 8 in [8,2048]", c);
+    const int tps = ctsi_gn_colsum_tiles(d, h, w);
+    if (tiles_per_sample) *tiles_per_sample = tps;
+    const int cpr = c / 8, rows_par = 256 / cpr;
+    const size_t lds = (size_t)rows_par * c * 2 * sizeof(float);
+    hipLaunchKernelGGL(gn_colsum_kernel, dim3(tps, n), dim3(256), lds, (hipStream_t)stream,
+                       (const bf16_t*)x, colsum, n, c, (long long)d * h * w, tps);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// ---- finalize: column-sum slab -> (sum, sumsq) per (sample, group), fp64 -----------------------
+// grid: (groups, n, slices); block 256.
+__global__ void __launch_bounds__(256)
+gn_finalize_kernel(const float* __restrict__ colsum, double* __restrict__ sums, int n_total, int c_pad,
+                   int groups, int cpg, int tps, int nclass, int tiles_per_slice) {
+    const int g = blockIdx.x, nb = blockIdx.y, slice = blockIdx.z;
+    const int tid = threadIdx.x;
+    const long long slab = (long long)nclass * n_total * tps * c_pad;
+    const int t0 = slice * tiles_per_slice;
+    int t1 = t0 + tiles_per_slice;
+    if (t1 > tps) t1 = tps;
+    double a1 = 0.0, a2 = 0.0;
+    const int items = (t1 - t0) * cpg;
+    for (int cls = 0; cls < nclass; ++cls) {
+        const long long tbase = ((long long)cls * n_total + nb) * tps;
+        for (int it = tid; it < items; it += 256) {
+            const int t = t0 + it / cpg, col = g * cpg + it % cpg;
+            const long long idx = (tbase + t) * c_pad + col;
+            a1 += (double)colsum[idx];
+            a2 += (double)colsum[slab + idx];
+        }
+    }
+    __shared__ double s1[256], s2[256];
+    s1[tid] = a1;
+    s2[tid] = a2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            s1[tid] += s1[tid + off];
+            s2[tid] += s2[tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        atomicAdd(&sums[((long long)nb * groups + g) * 2 + 0], s1[0]);
+        atomicAdd(&sums[((long long)nb * groups + g) * 2 + 1], s2[0]);
+    }
+}
+
+extern "C" int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c, int c_pad, int groups,
+                                int tiles_per_sample, int nclass, void* stream) {
+    CTSI_CHECK_ARG(colsum && sums, "ctsi_gn_finalize: null argument");
+    CTSI_CHECK_ARG(groups > 0 && c % groups == 0, "ctsi_gn_finalize: c=%d not divisible by groups=%d", c, groups);
+    const int cpg = c / groups;
+    int per_slice = 4096 / cpg;  // ~4096 floats per block and statistic
+    if (per_slice < 1) per_slice = 1;
+    const int slices = ceil_div(tiles_per_sample, per_slice);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n, slices), dim3(256), 0, (hipStream_t)stream, colsum,
+                       sums, n, c_pad, groups, cpg, tiles_per_sample, nclass, per_slice);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// ---- apply --------------------------------------------------------------------------------------
+// grid: (blocks_per_sample, n); block 256.  scale/shift for the sample's channels live in LDS.
+__global__ void __launch_bounds__(256)
+gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const double* __restrict__ sums,
+                const float* __restrict__ gamma, const float* __restrict__ beta, int c, long long vox,
+                int groups, float eps, int silu_pre, const float* __restrict__ tbias, int tbias_stride,
+                const int* __restrict__ step_ptr, int n_total, const bf16_t* __restrict__ residual,
+                int silu_post) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_scale = reinterpret_cast<float*>(smem_raw);
+    float* s_shift = s_scale + c;
+    float* s_tb = s_shift + c;
+    const int nb = blockIdx.y, tid = threadIdx.x;
+    const int cpg = c / groups;
+    const double cnt = (double)cpg * (double)vox;
+    long long trow = nb;
+    if (step_ptr) trow += (long long)(*step_ptr) * n_total;
+    for (int ch = tid; ch < c; ch += 256) {
+        const int g = ch / cpg;
+        const double m = sums[((long long)nb * groups + g) * 2 + 0] / cnt;
+        double var = sums[((long long)nb * groups + g) * 2 + 1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[ch] * rstd;
+        s_scale[ch] = sc;
+        s_shift[ch] = beta[ch] - (float)m * sc;
+        s_tb[ch] = tbias ? tbias[trow * tbias_stride + ch] : 0.0f;
+    }
+    __syncthreads();
+    const int cpr = c >> 3;
+    const long long total = vox * cpr;
+    const bf16_t* xb = x + (long long)nb * vox * c;
+    bf16_t* yb = y + (long long)nb * vox * c;
+    const bf16_t* rb = residual ? residual + (long long)nb * vox * c : nullptr;
+    for (long long e = (long long)blockIdx.x * 256 + tid; e < total; e += (long long)gridDim.x * 256) {
+        const int q = (int)(e % cpr);
+        const uint4 raw = *reinterpret_cast<const uint4*>(xb + e * 8);
+        float f[8], r[8];
+        unpack8(raw, f);
+        if (rb) unpack8(*reinterpret_cast<const uint4*>(rb + e * 8), r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ch = q * 8 + k;
+            float v = f[k] * s_scale[ch] + s_shift[ch];
+            if (silu_pre) v = silu_f(v);
+            v += s_tb[ch];
+            if (rb) v += r[k];
+            if (silu_post) v = silu_f(v);
+            f[k] = v;
+        }
+        *reinterpret_cast<uint4*>(yb + e * 8) = pack8(f);
+    }
+}
+
+extern "C" int ctsi_gn_apply(const void* x, void* y, const double* sums, const float* gamma, const float* beta,
+                             int n, int c, int d, int h, int w, int groups, float eps, int silu_pre,
+                             const float* tbias, int tbias_stride, const int* step_ptr,
+                             const void* residual, int silu_post, void* stream) {
+    CTSI_CHECK_ARG(x && y && sums && gamma && beta, "ctsi_gn_apply: null argument");
+    CTSI_CHECK_ARG(c % 8 == 0 && groups > 0 && c % groups == 0, "ctsi_gn_apply: bad c=%d groups=%d", c, groups);
+    const long long vox = (long long)d * h * w;
+    const long long total = vox * (c / 8);
+    long long blocks = (total + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    const size_t lds = (size_t)c * 3 * sizeof(float);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, n), dim3(256), lds, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, sums, gamma, beta, c, vox, groups, eps, silu_pre, tbias,
+                       tbias_stride, step_ptr, n, (const bf16_t*)residual, silu_post);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}

@@ -1,0 +1,110 @@
+"""GaussianDiffusion — schedules and DDPM sampling (mirror of reference models/diffusion.py).
+
+The ten (timesteps,) fp32 buffers are built with the same torch ops, in the same order, as the
+reference (diffusion.py:27-79) so they are bit-identical and checkpoint-compatible.  The reverse
+process runs on the HIP engine: `p_sample_loop` drives a captured U-Net step graph and the
+ctsi_ddpm_step kernel.  `training_loss` (config 3) is outside this round's scope.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .lib import CtsiError
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, noise_schedule='cosine', timesteps=1000, beta_start=0.0001, beta_end=0.02):
+        super().__init__()
+        self.timesteps = timesteps
+        self.noise_schedule = noise_schedule
+        if noise_schedule == 'linear':
+            betas = self._linear_beta_schedule(timesteps, beta_start, beta_end)
+        elif noise_schedule == 'cosine':
+            betas = self._cosine_beta_schedule(timesteps)
+        else:
+            raise ValueError(f"Unknown noise schedule: {noise_schedule}")
+
+        alphas = 1.0 - betas
+        abar = torch.cumprod(alphas, dim=0)
+        abar_prev = F.pad(abar[:-1], (1, 0), value=1.0)
+        post_var = betas * (1.0 - abar_prev) / (1.0 - abar)
+        for name, value in (
+            ('betas', betas),
+            ('alphas', alphas),
+            ('alphas_cumprod', abar),
+            ('alphas_cumprod_prev', abar_prev),
+            ('sqrt_alphas_cumprod', torch.sqrt(abar)),
+            ('sqrt_one_minus_alphas_cumprod', torch.sqrt(1.0 - abar)),
+            ('posterior_variance', post_var),
+            ('posterior_log_variance_clipped', torch.log(torch.clamp(post_var, min=1e-20))),
+            ('posterior_mean_coef1', betas * torch.sqrt(abar_prev) / (1.0 - abar)),
+            ('posterior_mean_coef2', (1.0 - abar_prev) * torch.sqrt(alphas) / (1.0 - abar)),
+        ):
+            self.register_buffer(name, value)
+
+    def _linear_beta_schedule(self, timesteps, beta_start, beta_end):
+        return torch.linspace(beta_start, beta_end, timesteps)
+
+    def _cosine_beta_schedule(self, timesteps, s=0.008):
+        # abar(x) = cos^2(((x/T) + s)/(1+s) * pi/2), normalised by abar(0); beta clipped to [1e-4, 0.9999]
+        grid = torch.linspace(0, timesteps, timesteps + 1)
+        abar = torch.cos(((grid / timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
+        abar = abar / abar[0]
+        return torch.clip(1 - (abar[1:] / abar[:-1]), 0.0001, 0.9999)
+
+    def _extract(self, a, t, x_shape):
+        out = a.gather(-1, t).float()
+        return out.reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
+
+    # ---- forward process (elementwise, torch ops on whatever device the tensors live) --------------
+    def q_sample(self, z_0, t, noise=None):
+        if noise is None:
+            noise = torch.randn_like(z_0)
+        z_t = (self._extract(self.sqrt_alphas_cumprod, t, z_0.shape) * z_0 +
+               self._extract(self.sqrt_one_minus_alphas_cumprod, t, z_0.shape) * noise)
+        return z_t, noise
+
+    # ---- DDPM reverse process on the HIP engine -------------------------------------------------------
+    def ddpm_coef_rows(self, t_desc):
+        """Per-step coefficient rows for ctsi_ddpm_step, fp32 values taken from the registered buffers
+        exactly as p_mean_variance / p_sample read them (diffusion.py:290-336)."""
+        idx = torch.as_tensor(list(t_desc), dtype=torch.long, device=self.betas.device)
+        rows = torch.zeros(len(idx), 8, dtype=torch.float32, device=self.betas.device)
+        rows[:, 0] = self.sqrt_one_minus_alphas_cumprod[idx]
+        rows[:, 1] = self.sqrt_alphas_cumprod[idx]
+        rows[:, 2] = self.posterior_mean_coef1[idx]
+        rows[:, 3] = self.posterior_mean_coef2[idx]
+        rows[:, 4] = (idx != 0).float() * torch.exp(0.5 * self.posterior_log_variance_clipped[idx])
+        return rows
+
+    @torch.no_grad()
+    def p_sample_loop(self, model, shape, c, device, progress=True, noise_fn=None, num_steps=None):
+        """z_T ~ N(0, I); for t = T-1..0: one U-Net evaluation + ctsi_ddpm_step (clip to [-1, 1]).
+
+        `noise_fn(i, shape)` (optional, additive kwarg) supplies the initial noise (i = -1) and the
+        per-step noise tensors instead of torch.randn; `num_steps` truncates the loop to its first
+        steps (both are test hooks; defaults reproduce the reference)."""
+        from .sampler import run_sampler  # local import: sampler imports this module
+        return run_sampler(self, model, shape, c, device, kind="ddpm",
+                           t_desc=list(reversed(range(self.timesteps)))[:num_steps], progress=progress,
+                           noise_fn=noise_fn)
+
+    @torch.no_grad()
+    def p_sample(self, model, z_t, t, c, clip_denoised=True):
+        """One DDPM step (diffusion.py:310-338) for a batch-uniform t on the HIP engine."""
+        from .sampler import run_sampler
+        tv = [int(v) for v in t.reshape(-1).tolist()]
+        if len(set(tv)) != 1:
+            raise CtsiError("p_sample on the HIP engine needs the same timestep for every sample")
+        if not clip_denoised:
+            raise CtsiError("p_sample: clip_denoised=False is not supported by the HIP engine")
+        return run_sampler(self, model, tuple(z_t.shape), c, z_t.device, kind="ddpm", t_desc=[tv[0]],
+                           progress=False, z_init=z_t)
+
+    def training_loss(self, *args, **kwargs):
+        raise NotImplementedError("training_loss (reference diffusion.py:108-247) belongs to the training "
+                                  "forward/backward path, which this engine does not cover yet")

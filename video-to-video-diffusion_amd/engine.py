@@ -1,0 +1,753 @@
+"""Host-side execution engine: turns the reference's module trees (UNet3D, the VAE encoder and
+decoder) into flat programs of libctsi launches on one HIP stream, optionally captured into a
+hipGraph (one graph per denoising step).
+
+PyTorch is used here for device memory, the stream object and parameter storage only; every
+arithmetic op of the hot path is a libctsi kernel.  There is no CPU path: constructing a context
+without a HIP device (or without libctsi.so) raises ``CtsiError``.
+
+Data layout in HBM
+  activations   bf16, channels-last (n, d, h, w, c), c contiguous; 16-byte (8-channel) accesses
+  weights       bf16, re-laid out once per layer into the gather-GEMM image [class][cout_pad][K]
+  GN statistics fp32 per-tile column sums -> fp64 (sum, sumsq) per (sample, group)
+  sampler state fp32 NDHWC (z) + its bf16 copy inside the U-Net input tensor [z | cond]
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .lib import ConvDesc, ConvOut, CtsiError, get_lib
+
+_CTX: Dict[int, "Ctx"] = {}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class Ctx:
+    """Per-device engine context: the library handle and the engine's own HIP stream."""
+
+    def __init__(self, device: torch.device):
+        self.lib = get_lib()
+        if not torch.cuda.is_available() or not self.lib.device_available():
+            raise CtsiError("the HIP engine needs a ROCm device; none is visible to this process")
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.sptr = C.c_void_p(self.stream.cuda_stream)
+
+    @staticmethod
+    def get(device) -> "Ctx":
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise CtsiError(
+                f"the HIP engine runs on ROCm devices only (got device '{device}'); there is no CPU path")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in _CTX:
+            _CTX[idx] = Ctx(torch.device("cuda", idx))
+        return _CTX[idx]
+
+    # make the engine stream wait for work queued on torch's current stream, and vice versa
+    def enter(self):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def leave(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    @contextlib.contextmanager
+    def scope(self):
+        """Run a block on the engine stream, ordered after/before the caller's current stream."""
+        self.enter()
+        with torch.cuda.stream(self.stream):
+            yield self
+        self.leave()
+
+
+class _Pool:
+    """Tiny size-keyed buffer pool used while a program is being laid out (ops run in stream
+    order, so a buffer may be handed out again as soon as its last reader has been emitted)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free: Dict[Tuple[int, torch.dtype], List[torch.Tensor]] = {}
+        self.total_bytes = 0
+
+    def get(self, numel: int, dtype: torch.dtype) -> torch.Tensor:
+        lst = self.free.get((numel, dtype))
+        if lst:
+            return lst.pop()
+        self.total_bytes += numel * torch.empty(0, dtype=dtype).element_size()
+        return torch.empty(numel, dtype=dtype, device=self.device)
+
+    def put(self, t: torch.Tensor):
+        self.free.setdefault((t.numel(), t.dtype), []).append(t)
+
+
+class Act:
+    """A bf16 NDHWC activation buffer with its logical shape."""
+    __slots__ = ("t", "n", "c", "d", "h", "w")
+
+    def __init__(self, t, n, c, d, h, w):
+        self.t, self.n, self.c, self.d, self.h, self.w = t, n, c, d, h, w
+
+    @property
+    def vox(self):
+        return self.d * self.h * self.w
+
+
+class Program:
+    """A flat list of libctsi launches plus the buffers they touch."""
+
+    def __init__(self, ctx: Ctx):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.ops: List[Callable[[], None]] = []
+        self.pool = _Pool(ctx.device)
+        self.keep: List[object] = []       # tensors / ctypes structs that must outlive the ops
+        self.plans: List[C.c_void_p] = []  # conv plan handles (destroyed with the program)
+        self.pack_fns: List[Callable[[], None]] = []
+        self.flops = 0.0
+        self.conv_flops: List[Tuple[str, float]] = []
+        self.gn_slots = 0
+        self._gn_sums: Optional[torch.Tensor] = None
+        self._colsum: Optional[torch.Tensor] = None
+        self._colsum_need = 0
+        self._gn_need: List[Tuple[int, int]] = []
+        self.graph = None
+        self._params: List[torch.Tensor] = []
+        self._versions: Tuple[int, ...] = ()
+
+    # ---- buffers -------------------------------------------------------------------------------------
+    def act(self, n, c, d, h, w) -> Act:
+        return Act(self.pool.get(n * c * d * h * w, torch.bfloat16), n, c, d, h, w)
+
+    def release(self, a: Act):
+        self.pool.put(a.t)
+
+    def persistent(self, shape, dtype, zero=False) -> torch.Tensor:
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.ctx.device)
+        self.keep.append(t)
+        return t
+
+    # ---- parameters ------------------------------------------------------------------------------------
+    def track(self, *params: torch.Tensor):
+        self._params.extend(params)
+
+    def dev_f32(self, make: Callable[[], torch.Tensor]) -> torch.Tensor:
+        """A persistent fp32 device copy of a (derived) parameter, refreshed by repack()."""
+        src = make().detach()
+        buf = torch.empty(src.shape, dtype=torch.float32, device=self.ctx.device)
+        self.keep.append(buf)
+
+        def refresh():
+            buf.copy_(make().detach().to(device=self.ctx.device, dtype=torch.float32))
+
+        self.pack_fns.append(refresh)
+        return buf
+
+    def repack(self):
+        with torch.cuda.stream(self.ctx.stream):
+            for fn in self.pack_fns:
+                fn()
+        self._versions = tuple(p._version for p in self._params)
+
+    def ensure_fresh(self):
+        if tuple(p._version for p in self._params) != self._versions:
+            self.repack()
+
+    # ---- conv ----------------------------------------------------------------------------------------------
+    def conv(self, name: str, weight_fn, bias_fn, x1: Act, x2: Optional[Act], *, transposed=False,
+             k=(3, 3, 3), s=(1, 1), p=(1, 1, 1), cout: int, cin_w: Optional[int] = None,
+             out: Optional[Act] = None, want_stats=False, f32_out: Optional[torch.Tensor] = None,
+             f32_strides: Optional[Sequence[int]] = None, act: int = 0):
+        """Emit one convolution.  weight_fn/bias_fn return the *current* fp32 parameter tensors
+        (possibly derived, e.g. scaled or pre-multiplied).  Returns (out_act, stats_handle)."""
+        lib = self.lib
+        desc = ConvDesc(int(transposed), k[0], k[1], k[2], s[0], s[1], p[0], p[1], p[2], x1.n, x1.c,
+                        0 if x2 is None else x2.c, cout, x1.d, x1.h, x1.w)
+        plan = C.c_void_p()
+        lib.conv_plan_create(C.byref(plan), C.byref(desc))
+        self.plans.append(plan)
+        if cin_w is not None:
+            lib.conv_plan_set_weight_cin(plan, cin_w)
+        do, ho, wo = C.c_int(), C.c_int(), C.c_int()
+        lib.conv_plan_out_dims(plan, C.byref(do), C.byref(ho), C.byref(wo))
+        do, ho, wo = do.value, ho.value, wo.value
+        wbytes = lib.conv_plan_weight_bytes(plan)
+        packed = torch.empty(wbytes, dtype=torch.uint8, device=self.ctx.device)
+        self.keep.append(packed)
+        bias = self.dev_f32(bias_fn) if bias_fn is not None else None
+        sptr = self.ctx.sptr
+
+        def pack():
+            wt = weight_fn().detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+            lib.conv_plan_pack_weights(plan, _ptr(wt), _ptr(packed), sptr)
+            wt.record_stream(self.ctx.stream)
+
+        self.pack_fns.append(pack)
+        fl = lib.conv_plan_flops(plan)
+        self.flops += fl
+        self.conv_flops.append((name, fl))
+
+        stats = None
+        colsum_ptr = 0
+        if want_stats:
+            tiles = lib.conv_plan_tiles(plan)
+            cpad = lib.conv_plan_cout_pad(plan)
+            self._colsum_need = max(self._colsum_need, 2 * tiles * cpad)
+            stats = dict(tps=lib.conv_plan_tiles_per_sample(plan), cpad=cpad,
+                         nclass=4 if transposed else 1)
+        co = ConvOut()
+        if f32_out is not None:
+            co.y = f32_out.data_ptr()
+            co.mode = 1
+            co.sn, co.sc, co.sd, co.sh, co.sw = [int(v) for v in f32_strides]
+            out_act = None
+        else:
+            if out is None:
+                out = self.act(x1.n, cout, do, ho, wo)
+            co.y = out.t.data_ptr()
+            co.mode = 0
+            co.cout_stride = out.c
+            co.c_off = 0
+            out_act = out
+        co.act = act
+        self.keep.append(co)
+        x1p, x2p, wp, bp = _ptr(x1.t), _ptr(None if x2 is None else x2.t), _ptr(packed), _ptr(bias)
+        prog = self
+
+        def run():
+            co.colsum = prog._colsum.data_ptr() if want_stats else 0
+            lib.conv_fwd(plan, x1p, x2p, wp, bp, C.byref(co), sptr)
+
+        self.ops.append(run)
+        return out_act, stats
+
+    # ---- GroupNorm ----------------------------------------------------------------------------------------
+    def _gn_slot(self, n, groups) -> int:
+        off = self.gn_slots
+        self.gn_slots += n * groups * 2
+        return off
+
+    def gn_finalize(self, x: Act, groups: int, stats: dict) -> int:
+        """colsum slab (already written by the producer) -> fp64 sums slot; returns the slot offset."""
+        slot = self._gn_slot(x.n, groups)
+        lib, sptr, prog = self.lib, self.ctx.sptr, self
+        n, c = x.n, x.c
+        tps, cpad, nclass = stats["tps"], stats["cpad"], stats["nclass"]
+
+        def run():
+            lib.gn_finalize(_ptr(prog._colsum), C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), n, c, cpad,
+                            groups, tps, nclass, sptr)
+
+        self.ops.append(run)
+        return slot
+
+    def gn_colsum(self, x: Act) -> dict:
+        lib, sptr, prog = self.lib, self.ctx.sptr, self
+        tps = lib.gn_colsum_tiles(x.d, x.h, x.w)
+        self._colsum_need = max(self._colsum_need, 2 * x.n * tps * x.c)
+        xp = _ptr(x.t)
+        n, c, d, h, w = x.n, x.c, x.d, x.h, x.w
+
+        def run():
+            lib.gn_colsum(xp, _ptr(prog._colsum), n, c, d, h, w, None, sptr)
+
+        self.ops.append(run)
+        return dict(tps=tps, cpad=x.c, nclass=1)
+
+    def gn_apply(self, x: Act, slot: int, gn: nn.GroupNorm, *, silu_pre: bool, tbias=None,
+                 tbias_off: int = 0, tbias_stride: int = 0, step_ptr: Optional[torch.Tensor] = None,
+                 residual: Optional[Act] = None, silu_post: bool = False, out: Optional[Act] = None) -> Act:
+        lib, sptr, prog = self.lib, self.ctx.sptr, self
+        gamma = self.dev_f32(lambda: gn.weight)
+        beta = self.dev_f32(lambda: gn.bias)
+        self.track(gn.weight, gn.bias)
+        if out is None:
+            out = self.act(x.n, x.c, x.d, x.h, x.w)
+        xp, yp, gp, bp = _ptr(x.t), _ptr(out.t), _ptr(gamma), _ptr(beta)
+        tbp = C.c_void_p(0 if tbias is None else tbias.data_ptr() + tbias_off * 4)
+        stp = _ptr(step_ptr)
+        rp = _ptr(None if residual is None else residual.t)
+        n, c, d, h, w, groups, eps = x.n, x.c, x.d, x.h, x.w, gn.num_groups, float(gn.eps)
+
+        def run():
+            lib.gn_apply(xp, yp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, n, c, d, h, w, groups,
+                         eps, int(silu_pre), tbp, tbias_stride, stp, rp, int(silu_post), sptr)
+
+        self.ops.append(run)
+        return out
+
+    # ---- U-Net blocks ------------------------------------------------------------------------------------
+    def unet_resblock(self, m, x: Act, skip: Optional[Act], tbias: torch.Tensor, tbias_off: int,
+                      tbias_stride: int, step_ptr: Optional[torch.Tensor]) -> Act:
+        """ResBlock3D of the U-Net (models/unet3d.py:116-133); `skip` is the second half of a
+        channel concatenation feeding the block (never materialised)."""
+        cout = m.conv1.conv.out_channels
+        if isinstance(m.residual_conv, nn.Identity):
+            if skip is not None:
+                raise CtsiError("identity residual with a concatenated input")
+            r, own_r = x, False
+        else:
+            r, _ = self.conv("res1x1", lambda: m.residual_conv.weight, lambda: m.residual_conv.bias, x, skip,
+                             k=(1, 1, 1), p=(0, 0, 0), cout=cout)
+            own_r = True
+        c1, st = self.conv("rb.conv1", lambda: m.conv1.conv.weight, lambda: m.conv1.conv.bias, x, skip,
+                           cout=cout, want_stats=True)
+        slot = self.gn_finalize(c1, m.conv1.norm.num_groups, st)
+        h1 = self.gn_apply(c1, slot, m.conv1.norm, silu_pre=True, tbias=tbias, tbias_off=tbias_off,
+                           tbias_stride=tbias_stride, step_ptr=step_ptr, out=c1)
+        c2, st = self.conv("rb.conv2", lambda: m.conv2[0].weight, lambda: m.conv2[0].bias, h1, None, cout=cout,
+                           want_stats=True)
+        self.release(h1)
+        slot = self.gn_finalize(c2, m.conv2[1].num_groups, st)
+        out = self.gn_apply(c2, slot, m.conv2[1], silu_pre=False, residual=r, silu_post=True, out=c2)
+        if own_r:
+            self.release(r)
+        return out
+
+    def attention(self, m, x: Act, mode: str = "fast") -> Act:
+        """TemporalAttention (models/unet3d.py:163-194), see csrc/attention.hip."""
+        lib, sptr, prog = self.lib, self.ctx.sptr, self
+        n, c, d, h, w = x.n, x.c, x.d, x.h, x.w
+        dev = self.ctx.device
+        heads = m.num_heads
+        tps = lib.attn_depthsum_tiles(c, h, w)
+        self._colsum_need = max(self._colsum_need, 2 * n * tps * c)
+        depthsum = self.pool.get(n * h * w * c, torch.float32)
+        xp, dsp = _ptr(x.t), _ptr(depthsum)
+
+        def run_ds():
+            lib.attn_depthsum(xp, dsp, _ptr(prog._colsum), n, c, d, h, w, sptr)
+
+        self.ops.append(run_ds)
+        slot = self.gn_finalize(x, m.norm.num_groups, dict(tps=tps, cpad=c, nclass=1))
+        gamma = self.dev_f32(lambda: m.norm.weight)
+        beta = self.dev_f32(lambda: m.norm.bias)
+        xs = self.act(n, c, 1, h, w)
+        groups, eps = m.norm.num_groups, float(m.norm.eps)
+        gp, bp, xsp = _ptr(gamma), _ptr(beta), _ptr(xs.t)
+
+        def run_ns():
+            lib.attn_normsum(dsp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, xsp, n, c, d, h, w,
+                             groups, eps, sptr)
+
+        self.ops.append(run_ns)
+
+        # fold proj_out . V-projection:  P = (Wp Wv) xs + (D Wp bv + bp)
+        def wv():
+            return m.qkv.weight[2 * c:3 * c, :, 0, 0, 0].double()
+
+        def wpv():
+            wp = m.proj_out.weight[:, :, 0, 0, 0].double()
+            return (wp @ wv()).float().reshape(c, c, 1, 1, 1)
+
+        def bpv():
+            wp = m.proj_out.weight[:, :, 0, 0, 0].double()
+            return (float(d) * (wp @ m.qkv.bias[2 * c:3 * c].double()) + m.proj_out.bias.double()).float()
+
+        pterm, _ = self.conv("attn.pv", wpv, bpv, xs, None, k=(1, 1, 1), p=(0, 0, 0), cout=c)
+        self.pool.put(depthsum)
+        self.release(xs)
+        rowsum = None
+        if mode == "exact":
+            # evaluate the softmax row sums the reference multiplies in (they equal 1 up to rounding)
+            xn = self.gn_apply(x, slot, m.norm, silu_pre=False)
+            qk, _ = self.conv("attn.qk", lambda: m.qkv.weight[:2 * c], lambda: m.qkv.bias[:2 * c], xn, None,
+                              k=(1, 1, 1), p=(0, 0, 0), cout=2 * c)
+            self.release(xn)
+            rowsum = self.pool.get(n * d * h * w * heads, torch.float32)
+            qkp, rsp = _ptr(qk.t), _ptr(rowsum)
+
+            def run_rs():
+                lib.attn_softmax_rowsum(qkp, rsp, n, c, d, h, w, heads, sptr)
+
+            self.ops.append(run_rs)
+            self.release(qk)
+        out = self.act(n, c, d, h, w)
+        pp, op_, rsp2 = _ptr(pterm.t), _ptr(out.t), _ptr(rowsum)
+
+        def run_ba():
+            lib.attn_broadcast_add(xp, pp, rsp2, heads, op_, n, c, d, h, w, sptr)
+
+        self.ops.append(run_ba)
+        self.release(pterm)
+        if rowsum is not None:
+            self.pool.put(rowsum)
+        return out
+
+    # ---- finish layout / execution ----------------------------------------------------------------------------
+    def finalize_layout(self):
+        dev = self.ctx.device
+        self._colsum = torch.empty(max(self._colsum_need, 1), dtype=torch.float32, device=dev)
+        self._gn_sums = torch.zeros(max(self.gn_slots, 1), dtype=torch.float64, device=dev)
+        self.repack()
+
+    def zero_gn_op(self):
+        lib, sptr, prog = self.lib, self.ctx.sptr, self
+
+        def run():
+            lib.memset_async(_ptr(prog._gn_sums), 0, prog._gn_sums.numel() * 8, sptr)
+
+        self.ops.append(run)
+
+    def run(self):
+        for op in self.ops:
+            op()
+
+    def capture(self):
+        lib = self.lib
+        lib.graph_begin_capture(self.ctx.sptr)
+        try:
+            self.run()
+        finally:
+            g = C.c_void_p()
+            lib.graph_end_capture(self.ctx.sptr, C.byref(g))
+        self.graph = g
+
+    def launch(self):
+        if self.graph is None:
+            self.run()
+        else:
+            self.lib.graph_launch(self.graph, self.ctx.sptr)
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                self.lib.graph_destroy(self.graph)
+            for p in self.plans:
+                self.lib.conv_plan_destroy(p)
+        except Exception:
+            pass
+
+
+# ==========================================================================================================
+# U-Net
+# ==========================================================================================================
+class UNetProgram(Program):
+    """One U-Net evaluation (models/unet3d.py:357-413) at a fixed latent shape, followed optionally by
+    a sampler update; `step_ptr` selects the timestep row, so one captured graph serves all steps."""
+
+    def __init__(self, ctx: Ctx, unet, n: int, d: int, h: int, w: int, max_rows: int, attention_mode="fast"):
+        super().__init__(ctx)
+        self.unet = unet
+        self.n, self.d, self.h, self.w = n, d, h, w
+        L = unet.latent_dim
+        self.L = L
+        dev = ctx.device
+        self.attention_mode = attention_mode
+        self.max_rows = max_rows
+        self.xin = Act(self.persistent((n * d * h * w * 2 * L,), torch.bfloat16, zero=True), n, 2 * L, d, h, w)
+        self.eps = self.persistent((n, d, h, w, L), torch.float32)
+        self.z = self.persistent((n, d, h, w, L), torch.float32, zero=True)
+        self.step_ptr = self.persistent((1,), torch.int32, zero=True)
+        self.t_rows = self.persistent((max_rows,), torch.int32, zero=True)
+        self.coef = self.persistent((max_rows, 8), torch.float32, zero=True)
+        self.noise = None  # fp32 NCDHW, allocated on demand
+        self.track(*[p for p in unet.parameters()])
+
+        # ---- time embedding: stack every ResBlock's Linear(time_dim -> cout) -------------------------
+        te = unet.time_embed.time_mlp
+        self.dim = unet.model_channels
+        self.time_dim = te[1].out_features
+        blocks = [m for m in unet.modules() if type(m).__name__ == "ResBlock3D"]
+        self.tb_off = {}
+        off = 0
+        for m in blocks:
+            self.tb_off[id(m)] = off
+            off += m.time_mlp[1].out_features
+        self.total_out = off
+        self.w1 = self.dev_f32(lambda: te[1].weight)
+        self.b1 = self.dev_f32(lambda: te[1].bias)
+        self.w2 = self.dev_f32(lambda: te[3].weight)
+        self.b2 = self.dev_f32(lambda: te[3].bias)
+        self.w_all = self.dev_f32(lambda: torch.cat([m.time_mlp[1].weight for m in blocks], 0))
+        self.b_all = self.dev_f32(lambda: torch.cat([m.time_mlp[1].bias for m in blocks], 0))
+        self.tbias = self.persistent((max_rows, self.total_out), torch.float32, zero=True)
+        self.te_scratch = self.persistent((max_rows * (self.dim + 2 * self.time_dim),), torch.float32)
+
+        # ---- network ------------------------------------------------------------------------------------
+        self.zero_gn_op()
+        x, _ = self.conv("conv_in", lambda: unet.conv_in.weight, lambda: unet.conv_in.bias, self.xin, None,
+                         cout=unet.conv_in.out_channels)
+        skips: List[Act] = []
+
+        def step(layer, xcur: Act, skip: Optional[Act] = None) -> Act:
+            ynew = self._layer(layer, xcur, skip)
+            if not any(xcur is sk for sk in skips):
+                self.release(xcur)
+            if skip is not None:
+                self.release(skip)
+            return ynew
+
+        for level_blocks, down in zip(unet.down_blocks, unet.down_samples):
+            for block_list in level_blocks:
+                for layer in block_list:
+                    x = step(layer, x)
+            skips.append(x)  # stays allocated until the decoder has consumed it
+            if not isinstance(down, nn.Identity):
+                x, _ = self.conv("down", (lambda m=down: m.conv.weight), (lambda m=down: m.conv.bias), x, None,
+                                 k=(3, 4, 4), s=(2, 2), p=(1, 1, 1), cout=down.conv.out_channels)
+        x = step(unet.mid_block1, x)
+        x = step(unet.mid_attn, x)
+        x = step(unet.mid_block2, x)
+        for level_blocks, up in zip(unet.up_blocks, unet.up_samples):
+            for j, block_list in enumerate(level_blocks):
+                skip = skips.pop() if j == 0 else None
+                for layer in block_list:
+                    x = step(layer, x, skip)
+                    skip = None
+            if not isinstance(up, nn.Identity):
+                xo, _ = self.conv("up", (lambda m=up: m.conv.weight), (lambda m=up: m.conv.bias), x, None,
+                                  transposed=True, k=(3, 4, 4), s=(2, 2), p=(1, 1, 1),
+                                  cout=up.conv.out_channels)
+                self.release(x)
+                x = xo
+        gn, conv = unet.conv_out[0], unet.conv_out[2]
+        st = self.gn_colsum(x)
+        slot = self.gn_finalize(x, gn.num_groups, st)
+        y = self.gn_apply(x, slot, gn, silu_pre=True)
+        self.release(x)
+        vox = d * h * w
+        self.conv("conv_out", lambda: conv.weight, lambda: conv.bias, y, None, cout=L, f32_out=self.eps,
+                  f32_strides=(vox * L, 1, h * w * L, w * L, L))
+        self.release(y)
+        self.unet_op_count = len(self.ops)
+        self.finalize_layout()
+
+    def _layer(self, layer, x: Act, skip: Optional[Act]) -> Act:
+        kind = type(layer).__name__
+        if kind == "ResBlock3D":
+            return self.unet_resblock(layer, x, skip, self.tbias, self.tb_off[id(layer)], self.total_out,
+                                      self.step_ptr)
+        if kind == "TemporalAttention":
+            return self.attention(layer, x, self.attention_mode)
+        raise CtsiError(f"unsupported U-Net layer {kind}")
+
+    # -- inputs / schedule --
+    def load_latents(self, z_ncdhw: Optional[torch.Tensor], cond_ncdhw: Optional[torch.Tensor]):
+        lib, sptr = self.lib, self.ctx.sptr
+        n, L, d, h, w = self.n, self.L, self.d, self.h, self.w
+        if z_ncdhw is not None:
+            z = z_ncdhw.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+            lib.ncdhw_f32_to_ndhwc_f32(_ptr(z), _ptr(self.z), n, L, d, h, w, sptr)
+            lib.ncdhw_f32_to_ndhwc_bf16(_ptr(z), _ptr(self.xin.t), n, L, d, h, w, 2 * L, 0, sptr)
+            z.record_stream(self.ctx.stream)
+        if cond_ncdhw is not None:
+            cnd = cond_ncdhw.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+            lib.ncdhw_f32_to_ndhwc_bf16(_ptr(cnd), _ptr(self.xin.t), n, L, d, h, w, 2 * L, L, sptr)
+            cnd.record_stream(self.ctx.stream)
+
+    def set_schedule(self, t_rows: Sequence[int], coef_rows: Optional[torch.Tensor] = None):
+        """Upload the timestep of every (step, sample) row, embed all of them in one go and rewind the
+        device-side step counter."""
+        rows = len(t_rows)
+        if rows > self.max_rows:
+            raise CtsiError(f"schedule needs {rows} rows but the program was built for {self.max_rows}")
+        lib, sptr = self.lib, self.ctx.sptr
+        self.ensure_fresh()
+        tt = torch.tensor(list(t_rows), dtype=torch.int32)
+        self.t_rows[:rows].copy_(tt, non_blocking=False)
+        if coef_rows is not None:
+            self.coef[:coef_rows.shape[0]].copy_(coef_rows.to(torch.float32))
+        self.step_ptr.zero_()
+        lib.time_embed_fwd(_ptr(self.t_rows), rows, self.dim, self.time_dim, _ptr(self.w1), _ptr(self.b1),
+                           _ptr(self.w2), _ptr(self.b2), _ptr(self.w_all), _ptr(self.b_all), self.total_out,
+                           _ptr(self.te_scratch), _ptr(self.tbias), sptr)
+
+    def eps_ncdhw(self) -> torch.Tensor:
+        out = torch.empty((self.n, self.L, self.d, self.h, self.w), dtype=torch.float32, device=self.ctx.device)
+        self.lib.ndhwc_f32_to_ncdhw_f32(_ptr(self.eps), _ptr(out), self.n, self.L, self.d, self.h, self.w,
+                                        self.ctx.sptr)
+        return out
+
+    def z_ncdhw(self) -> torch.Tensor:
+        out = torch.empty((self.n, self.L, self.d, self.h, self.w), dtype=torch.float32, device=self.ctx.device)
+        self.lib.ndhwc_f32_to_ncdhw_f32(_ptr(self.z), _ptr(out), self.n, self.L, self.d, self.h, self.w,
+                                        self.ctx.sptr)
+        return out
+
+    def add_sampler_step(self, kind: str, with_noise: bool):
+        """Append the DDIM/DDPM update and the step-counter increment (done once, before capture)."""
+        lib, sptr = self.lib, self.ctx.sptr
+        n, L, d, h, w = self.n, self.L, self.d, self.h, self.w
+        if with_noise and self.noise is None:
+            self.noise = self.persistent((n, L, d, h, w), torch.float32, zero=True)
+        fn = lib.ddim_step if kind == "ddim" else lib.ddpm_step
+        zp, ep, xp, cp, sp = _ptr(self.z), _ptr(self.eps), _ptr(self.xin.t), _ptr(self.coef), _ptr(self.step_ptr)
+        npz = _ptr(self.noise if with_noise else None)
+
+        def run_step():
+            fn(zp, ep, npz, xp, 2 * L, 0, cp, sp, n, L, d, h, w, sptr)
+
+        def run_adv():
+            lib.step_advance(sp, sptr)
+
+        self.ops.append(run_step)
+        self.ops.append(run_adv)
+        self.sampler_kind = (kind, with_noise)
+
+
+# ==========================================================================================================
+# VAE
+# ==========================================================================================================
+def _pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+class VAEEncodeProgram(Program):
+    """VideoEncoder.forward + scaling (models/vae.py:139-147, 235-247) at a fixed input shape."""
+
+    def __init__(self, ctx: Ctx, vae, n, d, h, w):
+        super().__init__(ctx)
+        enc = vae.encoder
+        self.n, self.d, self.h, self.w = n, d, h, w
+        cin = vae.in_channels
+        self.cin, self.cin_pad = cin, _pad8(cin)
+        self.track(*[p for p in enc.parameters()])
+        self.xin = Act(self.persistent((n * d * h * w * self.cin_pad,), torch.bfloat16, zero=True), n,
+                       self.cin_pad, d, h, w)
+        self.zero_gn_op()
+        x = self._conv_gn_act(enc.conv_in, self.xin, cin_w=cin, free=False)
+        for stage in (enc.down1, enc.down2):
+            for m in stage:
+                x = self._block(m, x)
+        for m in enc.mid:
+            x = self._block(m, x)
+        y, _ = self.conv("enc.conv_out", lambda: enc.conv_out.weight, lambda: enc.conv_out.bias, x, None,
+                         cout=enc.conv_out.out_channels)
+        self.release(x)
+        L = vae.latent_dim
+        self.L = L
+        hl, wl = y.h, y.w
+        self.hl, self.wl = hl, wl
+        self.out = self.persistent((n, L, d, hl, wl), torch.float32)
+        vox = d * hl * wl
+        sf = lambda: float(vae.scaling_factor)
+        self.conv("enc.quant", lambda: enc.quant_conv.weight * sf(), lambda: enc.quant_conv.bias * sf(), y, None,
+                  k=(1, 1, 1), p=(0, 0, 0), cout=L, f32_out=self.out,
+                  f32_strides=(L * vox, vox, hl * wl, wl, 1))
+        self.release(y)
+        self.finalize_layout()
+
+    def _conv_gn_act(self, m, x: Act, *, cin_w=None, free=True, k=(3, 3, 3), s=(1, 1), transposed=False) -> Act:
+        c, st = self.conv("conv+gn", lambda: m.conv.weight, lambda: m.conv.bias, x, None, k=k, s=s,
+                          transposed=transposed, cout=m.conv.out_channels, cin_w=cin_w, want_stats=True)
+        if free:
+            self.release(x)
+        slot = self.gn_finalize(c, m.norm.num_groups, st)
+        return self.gn_apply(c, slot, m.norm, silu_pre=True, out=c)
+
+    def _resblock(self, m, x: Act) -> Act:
+        c1, st = self.conv("rb.conv1", lambda: m.conv1.conv.weight, lambda: m.conv1.conv.bias, x, None,
+                           cout=x.c, want_stats=True)
+        slot = self.gn_finalize(c1, m.conv1.norm.num_groups, st)
+        h1 = self.gn_apply(c1, slot, m.conv1.norm, silu_pre=True, out=c1)
+        c2, st = self.conv("rb.conv2", lambda: m.conv2[0].weight, lambda: m.conv2[0].bias, h1, None, cout=x.c,
+                           want_stats=True)
+        self.release(h1)
+        slot = self.gn_finalize(c2, m.conv2[1].num_groups, st)
+        out = self.gn_apply(c2, slot, m.conv2[1], silu_pre=False, residual=x, silu_post=True, out=c2)
+        self.release(x)
+        return out
+
+    def _block(self, m, x: Act) -> Act:
+        kind = type(m).__name__
+        if kind == "ResBlock3D":
+            return self._resblock(m, x)
+        if kind == "DownsampleBlock":
+            return self._conv_gn_act(m, x, k=(3, 4, 4), s=(2, 2))
+        if kind == "UpsampleBlock":
+            return self._conv_gn_act(m, x, k=(3, 4, 4), s=(2, 2), transposed=True)
+        raise CtsiError(f"unsupported VAE block {kind}")
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        lib, sptr = self.lib, self.ctx.sptr
+        self.ensure_fresh()
+        xx = x.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        lib.ncdhw_f32_to_ndhwc_bf16(_ptr(xx), _ptr(self.xin.t), self.n, self.cin, self.d, self.h, self.w,
+                                    self.cin_pad, 0, sptr)
+        xx.record_stream(self.ctx.stream)
+        self.launch()
+        return self.out.clone()
+
+
+class VAEDecodeProgram(VAEEncodeProgram):
+    """VideoDecoder.forward + unscaling (models/vae.py:190-204, 249-260) at a fixed latent shape."""
+
+    def __init__(self, ctx: Ctx, vae, n, d, h, w):
+        Program.__init__(self, ctx)
+        dec = vae.decoder
+        self.n, self.d, self.h, self.w = n, d, h, w
+        L = vae.latent_dim
+        self.L, self.L_pad = L, _pad8(L)
+        self.track(*[p for p in dec.parameters()])
+        self.zin = Act(self.persistent((n * d * h * w * self.L_pad,), torch.bfloat16, zero=True), n, self.L_pad,
+                       d, h, w)
+        self.zero_gn_op()
+        inv = lambda: 1.0 / float(vae.scaling_factor)
+        x, _ = self.conv("dec.post_quant", lambda: dec.post_quant_conv.weight * inv(),
+                         lambda: dec.post_quant_conv.bias, self.zin, None, k=(1, 1, 1), p=(0, 0, 0),
+                         cout=dec.post_quant_conv.out_channels, cin_w=L)
+        x = self._conv_gn_act(dec.conv_in, x)
+        for m in dec.mid:
+            x = self._block(m, x)
+        x = self._block(dec.up2_upsample, x)
+        for m in dec.up2_res:
+            x = self._block(m, x)
+        x = self._block(dec.up3_upsample, x)
+        for m in dec.up3_res:
+            x = self._block(m, x)
+        co = dec.conv_out.out_channels
+        self.co = co
+        self.ho, self.wo = x.h, x.w
+        self.out = self.persistent((n, co, d, x.h, x.w), torch.float32)
+        vox = d * x.h * x.w
+        self.conv("dec.conv_out", lambda: dec.conv_out.weight, lambda: dec.conv_out.bias, x, None, cout=co,
+                  f32_out=self.out, f32_strides=(co * vox, vox, x.h * x.w, x.w, 1), act=1)
+        self.release(x)
+        self.finalize_layout()
+
+    def __call__(self, z: torch.Tensor) -> torch.Tensor:
+        lib, sptr = self.lib, self.ctx.sptr
+        self.ensure_fresh()
+        zz = z.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        lib.ncdhw_f32_to_ndhwc_bf16(_ptr(zz), _ptr(self.zin.t), self.n, self.L, self.d, self.h, self.w,
+                                    self.L_pad, 0, sptr)
+        zz.record_stream(self.ctx.stream)
+        self.launch()
+        return self.out.clone()
+
+
+# ==========================================================================================================
+# program caches hung off the modules
+# ==========================================================================================================
+def cached_program(module: nn.Module, key, build: Callable[[], Program]) -> Program:
+    cache = module.__dict__.setdefault("_ctsi_programs", {})
+    prog = cache.get(key)
+    if prog is None:
+        if len(cache) >= 4:  # programs own large activation buffers: keep a handful per module
+            cache.pop(next(iter(cache)))
+        prog = build()
+        cache[key] = prog
+    return prog
+
+
+def trilinear_depth(ctx: Ctx, z: torch.Tensor, d_out: int) -> torch.Tensor:
+    """F.interpolate(z, size=(d_out, h, w), mode='trilinear', align_corners=False) for fp32 NCDHW z."""
+    n, c, d, h, w = z.shape
+    zz = z.detach().to(device=ctx.device, dtype=torch.float32).contiguous()
+    out = torch.empty((n, c, d_out, h, w), dtype=torch.float32, device=ctx.device)
+    ctx.lib.trilinear_depth_fwd(_ptr(zz), None, n, c, d, d_out, h, w, c, 0, _ptr(out), ctx.sptr)
+    zz.record_stream(ctx.stream)
+    return out
+
+
+def nan_to_num_(ctx: Ctx, t: torch.Tensor) -> torch.Tensor:
+    ctx.lib.nan_to_num_f32(_ptr(t), t.numel(), ctx.sptr)
+    return t

@@ -1,0 +1,204 @@
+"""Headline benchmark: DDIM steps/sec (one step = one U-Net evaluation + the x_{t-1} update) on the
+8->48-slice @512x512 volume of BASELINE.json config 2, one volume per GPU.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  `value` = total steps/s over all ranks with the latent, the
+conditioning and every weight resident in HBM when the timed region starts.  The model is the one
+`VideoToVideoDiffusion(yaml.safe_load(config/slice_interpolation_full_medium.yaml))` builds in the
+reference (264.66 M-param U-Net, latent 8), random-init (seed 0), synthetic input.
+
+Extra objects on the same line:
+  roofline     — the dominant kernel (gather-GEMM MFMA conv, 128x128 tile): algorithmic conv FLOPs of
+                 one U-Net evaluation that this kernel executes / its summed launch time, measured
+                 with HIP events on the engine stream around every launch (eager pass, not the graph).
+  cpu_baseline — the CPU oracle (fp32 torch ops, all host cores) timed on a bounded sample:
+                 one U-Net evaluation on the config-1 latent (1,8,48,48,48); rank 0, N == 1 only.
+  volume_wall_s — wall-clock of the whole 8->48 @512^2 generate() (encode + 51 steps + decode).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+EFFECTIVE_CFG = {  # what the reference builds from its production YAML (U-Net keys fall back to defaults)
+    'model': {'in_channels': 1, 'latent_dim': 8, 'vae_base_channels': 128, 'vae_scaling_factor': 1.0},
+    'pretrained': {'use_pretrained': True, 'vae': {'enabled': True, 'checkpoint_path': 'unused'}},
+    'noise_schedule': 'cosine', 'diffusion_timesteps': 1000,
+}
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=51)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--hw", type=int, default=512, help="slice height/width (512 = config 2)")
+    ap.add_argument("--depth-in", type=int, default=8)
+    ap.add_argument("--depth-out", type=int, default=48)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=1, help="volumes per GPU")
+    ap.add_argument("--no-volume", action="store_true", help="skip the end-to-end generate() timing")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline():
+    """Oracle U-Net evaluation on the host cores (bounded sample: one evaluation, config-1 latent)."""
+    from oracle import ref_ops as R
+    pkg = importlib.import_module("video-to-video-diffusion_amd")
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    un = pkg.UNet3D(latent_dim=8).eval()
+    sd = {k: v.detach() for k, v in un.state_dict().items()}
+    cfg = dict(model_channels=128, num_res_blocks=2, attention_levels=[1, 2], channel_mult=[1, 2, 4, 4], num_heads=4)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 8, 48, 48, 48, generator=g)
+    c = torch.randn(1, 8, 48, 48, 48, generator=g)
+    t = torch.tensor([500])
+    with torch.no_grad():
+        t0 = time.time()
+        R.unet_forward(sd, cfg, x, t, c)
+        dt = time.time() - t0
+    flops_192, flops_512 = 4416.8e9, 31408.6e9
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "1 U-Net evaluation (fp32 torch CPU oracle) on the config-1 latent (1,8,48,48,48); "
+                      f"{dt:.2f} s, {flops_192 / dt / 1e9:.0f} GFLOP/s",
+            "equiv_512_steps_per_s": (flops_192 / dt) / flops_512}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("video-to-video-diffusion_amd")
+    S = importlib.import_module("video-to-video-diffusion_amd.sampler")
+    E = importlib.import_module("video-to-video-diffusion_amd.engine")
+
+    torch.manual_seed(0)
+    model = pkg.VideoToVideoDiffusion(EFFECTIVE_CFG).eval().to(dev)
+    n, L = args.batch, model.vae.latent_dim
+    d, h, w = args.depth_out, args.hw // 4, args.hw // 4
+    shape = (n, L, d, h, w)
+    gen = torch.Generator(device="cpu").manual_seed(1 + rank)
+    cond = torch.randn(shape, generator=gen).to(dev)
+    z_T = torch.randn(shape, generator=gen).to(dev)
+
+    ctx = E.Ctx.get(dev)
+    sampler = pkg.DDIMSampler(model.diffusion, model.unet)
+    t_desc = [int(t) for t in sampler._get_timesteps(args.ddim_steps)]          # 51 entries for 50 steps
+    total = args.warmup + args.steps
+    reps = (total + len(t_desc) - 1) // len(t_desc) + 1
+    with ctx.scope():
+        prog = E.UNetProgram(ctx, model.unet, n, d, h, w, max_rows=max(len(t_desc) * reps * n, n), attention_mode="fast")
+        prog.add_sampler_step("ddim", False)
+        prog.load_latents(z_T, cond)
+        coef = S.ddim_coef_rows(model.diffusion.alphas_cumprod, t_desc, 0.0).repeat(reps, 1)
+        t_rows = [t for _ in range(reps) for t in t_desc for _ in range(n)]
+        prog.set_schedule(t_rows, coef.to(dev))
+
+        roof = None
+        if not args.no_roofline:
+            prog.launch()  # touch everything once (eager)
+            prof = prog.profile_ops(repeats=2)
+            dom = [(fl, ms) for (_, k, fl, ms) in prof if k == "conv_mfma_128x128"]
+            allconv = [(fl, ms) for (_, k, fl, ms) in prof if k.startswith("conv_mfma")]
+            step_ms = sum(ms for *_, ms in prof)
+            fl_dom, ms_dom = sum(f for f, _ in dom), sum(m for _, m in dom)
+            roof = {"bound": "mfma", "kernel": "conv_gather_mfma_kernel<2,2,2,2,false> (128x128x64 tile)",
+                    "achieved": fl_dom / (ms_dom * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl_dom / (ms_dom * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                    "launches_per_step": len(dom), "avg_launch_ms": ms_dom / max(len(dom), 1),
+                    "flops_per_step_this_kernel": fl_dom,
+                    "flops_per_step_all_conv": sum(f for f, _ in allconv),
+                    "share_of_step_time": ms_dom / step_ms,
+                    "other_ops_ms": step_ms - sum(m for _, m in allconv)}
+            prog.load_latents(z_T, cond)
+            prog.set_schedule(t_rows, coef.to(dev))
+
+        prog.capture()
+        prog.step_ptr.zero_()
+        for _ in range(args.warmup):
+            prog.launch()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with ctx.scope():
+        for _ in range(args.steps):
+            prog.launch()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    with ctx.scope():
+        finite = bool(torch.isfinite(prog.z_ncdhw()).all().item())
+
+    unet_flops = prog.flops
+    del prog
+    model.unet.__dict__.pop("_ctsi_programs", None)
+    torch.cuda.empty_cache()
+
+    volume_wall = None
+    if not args.no_volume and world == 1:
+        v_in = (torch.rand(n, 1, args.depth_in, args.hw, args.hw, generator=gen) * 2 - 1).to(dev)
+        for rep in range(2):  # first pass builds/captures programs, second is the measurement
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            v_out = model.generate(v_in, 'ddim', num_inference_steps=args.ddim_steps, target_depth=args.depth_out)
+            torch.cuda.synchronize()
+            volume_wall = time.perf_counter() - t1
+        finite = finite and bool(torch.isfinite(v_out).all().item()) and tuple(v_out.shape) == (n, 1, args.depth_out,
+                                                                                                 args.hw, args.hw)
+
+    if rank == 0:
+        steps_total = args.steps * world * n
+        res = {
+            "metric": "ddim_steps_per_sec", "value": steps_total / dt, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"DDIM-{args.ddim_steps} step (U-Net eval + update) on latent {list(shape)} = "
+                                   f"{args.depth_in}->{args.depth_out} slices @{args.hw}x{args.hw}, effective 264.66M "
+                                   "U-Net (128x(1,2,4,4), latent 8), one volume per GPU, hipGraph-captured step",
+                       "volumes_per_gpu": n, "parallelism": f"dp{world}", "finite_outputs": finite,
+                       "unet_tflop_per_step": unet_flops / 1e12,
+                       "unet_tflops_achieved_per_gpu": unet_flops * args.steps / dt / 1e12},
+            "roofline": roof,
+            "cpu_baseline": None if (args.no_cpu or world > 1) else cpu_baseline(),
+            "volume_wall_s": volume_wall,
+        }
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,7 @@ class Program:
         self.ctx = ctx
         self.lib = ctx.lib
         self.ops: List[Callable[[], None]] = []
+        self.op_meta: List[Tuple[str, float, str]] = []
         self.pool = _Pool(ctx.device)
         self.keep: List[object] = []       # tensors / ctypes structs that must outlive the ops
         self.plans: List[C.c_void_p] = []  # conv plan handles (destroyed with the program)
@@ -121,6 +122,10 @@ class Program:
         self.graph = None
         self._params: List[torch.Tensor] = []
         self._versions: Tuple[int, ...] = ()
+
+    def _emit(self, fn: Callable[[], None], name: str = "op", flops: float = 0.0, kernel: str = ""):
+        self.ops.append(fn)
+        self.op_meta.append((name, flops, kernel))
 
     # ---- buffers -------------------------------------------------------------------------------------
     def act(self, n, c, d, h, w) -> Act:
@@ -225,7 +230,10 @@ class Program:
             co.colsum = prog._colsum.data_ptr() if want_stats else 0
             lib.conv_fwd(plan, x1p, x2p, wp, bp, C.byref(co), sptr)
 
-        self.ops.append(run)
+        cin = x1.c + (0 if x2 is None else x2.c)
+        small = cin <= 32 and (cin & (cin - 1)) == 0
+        kernel = ("conv_mfma_128x%d%s" % (128 if cout > 32 else 32, "_smallcin" if small else ""))
+        self._emit(run, name, fl, kernel)
         return out_act, stats
 
     # ---- GroupNorm ----------------------------------------------------------------------------------------
@@ -245,7 +253,7 @@ class Program:
             lib.gn_finalize(_ptr(prog._colsum), C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), n, c, cpad,
                             groups, tps, nclass, sptr)
 
-        self.ops.append(run)
+        self._emit(run, "gn.finalize")
         return slot
 
     def gn_colsum(self, x: Act) -> dict:
@@ -258,7 +266,7 @@ class Program:
         def run():
             lib.gn_colsum(xp, _ptr(prog._colsum), n, c, d, h, w, None, sptr)
 
-        self.ops.append(run)
+        self._emit(run, "gn.colsum")
         return dict(tps=tps, cpad=x.c, nclass=1)
 
     def gn_apply(self, x: Act, slot: int, gn: nn.GroupNorm, *, silu_pre: bool, tbias=None,
@@ -280,7 +288,7 @@ class Program:
             lib.gn_apply(xp, yp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, n, c, d, h, w, groups,
                          eps, int(silu_pre), tbp, tbias_stride, stp, rp, int(silu_post), sptr)
 
-        self.ops.append(run)
+        self._emit(run, "gn.apply")
         return out
 
     # ---- U-Net blocks ------------------------------------------------------------------------------------
@@ -325,7 +333,7 @@ class Program:
         def run_ds():
             lib.attn_depthsum(xp, dsp, _ptr(prog._colsum), n, c, d, h, w, sptr)
 
-        self.ops.append(run_ds)
+        self._emit(run_ds, "attn.depthsum")
         slot = self.gn_finalize(x, m.norm.num_groups, dict(tps=tps, cpad=c, nclass=1))
         gamma = self.dev_f32(lambda: m.norm.weight)
         beta = self.dev_f32(lambda: m.norm.bias)
@@ -337,7 +345,7 @@ class Program:
             lib.attn_normsum(dsp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, xsp, n, c, d, h, w,
                              groups, eps, sptr)
 
-        self.ops.append(run_ns)
+        self._emit(run_ns, "attn.normsum")
 
         # fold proj_out . V-projection:  P = (Wp Wv) xs + (D Wp bv + bp)
         def wv():
@@ -367,7 +375,7 @@ class Program:
             def run_rs():
                 lib.attn_softmax_rowsum(qkp, rsp, n, c, d, h, w, heads, sptr)
 
-            self.ops.append(run_rs)
+            self._emit(run_rs, "attn.softmax_rowsum")
             self.release(qk)
         out = self.act(n, c, d, h, w)
         pp, op_, rsp2 = _ptr(pterm.t), _ptr(out.t), _ptr(rowsum)
@@ -375,7 +383,7 @@ class Program:
         def run_ba():
             lib.attn_broadcast_add(xp, pp, rsp2, heads, op_, n, c, d, h, w, sptr)
 
-        self.ops.append(run_ba)
+        self._emit(run_ba, "attn.broadcast_add")
         self.release(pterm)
         if rowsum is not None:
             self.pool.put(rowsum)
@@ -394,11 +402,35 @@ class Program:
         def run():
             lib.memset_async(_ptr(prog._gn_sums), 0, prog._gn_sums.numel() * 8, sptr)
 
-        self.ops.append(run)
+        self._emit(run, "gn.zero")
 
     def run(self):
         for op in self.ops:
             op()
+
+    def profile_ops(self, repeats: int = 1):
+        """Eager run with a HIP event pair around every op (on the engine stream).  Returns a list of
+        (name, kernel, flops, milliseconds) — used by bench.py for the live roofline figure."""
+        lib, sptr = self.lib, self.ctx.sptr
+        nops = len(self.ops)
+        evs = []
+        for _ in range(nops + 1):
+            e = C.c_void_p()
+            lib.event_create(C.byref(e))
+            evs.append(e)
+        acc = [0.0] * nops
+        for _ in range(repeats):
+            lib.event_record(evs[0], sptr)
+            for i, op in enumerate(self.ops):
+                op()
+                lib.event_record(evs[i + 1], sptr)
+            for i in range(nops):
+                ms = C.c_float()
+                lib.event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms))
+                acc[i] += ms.value
+        for e in evs:
+            lib.event_destroy(e)
+        return [(m[0], m[2], m[1], acc[i] / repeats) for i, m in enumerate(self.op_meta)]
 
     def capture(self):
         lib = self.lib
@@ -588,8 +620,8 @@ class UNetProgram(Program):
         def run_adv():
             lib.step_advance(sp, sptr)
 
-        self.ops.append(run_step)
-        self.ops.append(run_adv)
+        self._emit(run_step, "sampler.step")
+        self._emit(run_adv, "sampler.advance")
         self.sampler_kind = (kind, with_noise)
 
 

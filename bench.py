@@ -50,14 +50,15 @@ def parse():
     ap.add_argument("--no-volume", action="store_true", help="skip the end-to-end generate() timing")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU oracle leg")
     return ap.parse_args()
 
 
-def cpu_baseline():
+def cpu_baseline(threads):
     """Oracle U-Net evaluation on the host cores (bounded sample: one evaluation, config-1 latent)."""
     from oracle import ref_ops as R
     pkg = importlib.import_module("video-to-video-diffusion_amd")
-    cores = os.cpu_count() or 1
+    cores = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     un = pkg.UNet3D(latent_dim=8).eval()
@@ -192,7 +193,7 @@ def main():
                        "unet_tflop_per_step": unet_flops / 1e12,
                        "unet_tflops_achieved_per_gpu": unet_flops * args.steps / dt / 1e12},
             "roofline": roof,
-            "cpu_baseline": None if (args.no_cpu or world > 1) else cpu_baseline(),
+            "cpu_baseline": None if (args.no_cpu or world > 1) else cpu_baseline(args.cpu_threads),
             "volume_wall_s": volume_wall,
         }
         print(json.dumps(res))

@@ -52,7 +52,7 @@ def timestep_sincos(t: torch.Tensor, dim: int) -> torch.Tensor:
     """ref models/unet3d.py:25-32"""
     half = dim // 2
     scale = math.log(10000) / (half - 1)
-    freqs = torch.exp(torch.arange(half) * -scale)
+    freqs = torch.exp(torch.arange(half, device=t.device) * -scale)
     args = t[:, None] * freqs[None, :]
     return torch.cat((args.sin(), args.cos()), dim=-1)
 
@@ -305,29 +305,49 @@ def psnr(a, b, max_val: float) -> float:
     return float(torch.clamp(val, 0.0, 100.0))
 
 
-# ---- deterministic, machine-independent weights --------------------------------------------------------
+# ---- deterministic, machine-independent pseudo-random data ----------------------------------------------
+def _hash_uniform(numel: int, key: float) -> torch.Tensor:
+    """u[i] = frac(sin(12.9898 i + key) * 43758.5453) in float64: white, reproducible on any machine
+    (no RNG state), so the golden generator and the tests rebuild identical tensors."""
+    i = torch.arange(numel, dtype=torch.float64)
+    v = torch.sin(i * 12.9898 + key) * 43758.5453
+    return v - torch.floor(v)
+
+
+def formula_input(shape, k: int) -> torch.Tensor:
+    """uniform(-sqrt(3), sqrt(3)) (unit variance) test input number k"""
+    n = int(np.prod(shape))
+    return ((2.0 * _hash_uniform(n, 78.233 * (k + 1)) - 1.0) * math.sqrt(3.0)).reshape(shape).float()
+
+
+def formula_noise(step: int, shape) -> torch.Tensor:
+    """approximately N(0,1) injected sampler noise for draw `step` (-1 = initial latent)"""
+    n = int(np.prod(shape))
+    acc = sum(_hash_uniform(n, 31.7 * (step + 3) + 7.13 * j) for j in range(4))
+    return ((acc - 2.0) * math.sqrt(3.0)).reshape(shape).float()
+
+
 def formula_state_dict(shapes: Dict[str, Sequence[int]], seed: int = 0) -> SD:
-    """w.flat[i] = a * sin(0.37 i + k): identical in the golden generator (build container) and on the
-    GPU box, so fixtures carry expected outputs only.  Norm weights ~1, biases small, conv/linear
-    weights scaled by 1/sqrt(fan_in) so activations stay O(1)."""
+    """Pseudo-random weights in PyTorch's default-init ranges (uniform +-1/sqrt(fan_in) for conv/linear
+    weights and biases, GroupNorm weight 1 +- 0.1, bias +-0.1), generated from a closed formula so that
+    fixtures carry expected outputs only."""
     sd = {}
     for n, (name, shape) in enumerate(shapes.items()):
         shape = tuple(shape)
         numel = int(np.prod(shape)) if len(shape) else 1
-        i = torch.arange(numel, dtype=torch.float64)
-        base = torch.sin(0.37 * i + 1.3 * n + 0.11 * seed)
+        u = 2.0 * _hash_uniform(numel, 3.11 * (n + 1) + 0.77 * seed) - 1.0
         is_norm = (".norm." in name or ".conv2.1." in name or "conv_out.0." in name) and len(shape) == 1
-        if name.endswith(".weight") and is_norm:
-            v = 1.0 + 0.1 * base
-        elif name.endswith(".bias"):
-            v = 0.05 * base
+        if is_norm:
+            v = (1.0 + 0.1 * u) if name.endswith(".weight") else 0.1 * u
         elif name.endswith(".weight"):
             if "up_samples" in name or "upsample" in name:   # ConvTranspose3d: (cin, cout, k...)
                 fan_in = shape[0] * int(np.prod(shape[2:])) / 4.0
             else:
                 fan_in = int(np.prod(shape[1:]))
-            v = base * (1.7 / math.sqrt(max(fan_in, 1)))
+            v = u / math.sqrt(max(fan_in, 1))
+        elif name.endswith(".bias"):
+            v = 0.1 * u
         else:
-            v = base
+            v = u
         sd[name] = v.reshape(shape).float()
     return sd

@@ -37,16 +37,8 @@ torch.set_num_threads(8)
 out = {}
 
 
-def formula_input(shape, k):
-    n = int(np.prod(shape))
-    i = torch.arange(n, dtype=torch.float64)
-    return (torch.sin(0.173 * i + 0.9 * k) + 0.3 * torch.cos(0.0071 * i * (k + 1))).reshape(shape).float()
-
-
-def formula_noise(step, shape):
-    n = int(np.prod(shape))
-    i = torch.arange(n, dtype=torch.float64)
-    return (1.41 * torch.sin(0.9131 * i + 1.7 * (step + 2))).reshape(shape).float()
+formula_input = R.formula_input
+formula_noise = R.formula_noise
 
 
 def load_formula(module, seed=0):

@@ -1,20 +1,12 @@
-"""Shared test utilities: the formula inputs/noise of tests/golden/make_golden.py, restated."""
+"""Shared test utilities (formula inputs / noise / weights come from oracle.ref_ops)."""
 import numpy as np
 import torch
 
 from oracle import ref_ops as R
 
 
-def formula_input(shape, k):
-    n = int(np.prod(shape))
-    i = torch.arange(n, dtype=torch.float64)
-    return (torch.sin(0.173 * i + 0.9 * k) + 0.3 * torch.cos(0.0071 * i * (k + 1))).reshape(shape).float()
-
-
-def formula_noise(step, shape):
-    n = int(np.prod(shape))
-    i = torch.arange(n, dtype=torch.float64)
-    return (1.41 * torch.sin(0.9131 * i + 1.7 * (step + 2))).reshape(shape).float()
+formula_input = R.formula_input
+formula_noise = R.formula_noise
 
 
 def formula_sd(module, seed):

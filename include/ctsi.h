@@ -105,6 +105,9 @@ int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* plan);
 int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* plan);
 /* algorithmic FLOPs (2*MAC, dense direct convolution) of one forward of this layer */
 double ctsi_conv_plan_flops(const ctsi_conv_plan* plan);
+/* which kernel variant the plan launches: MFMA tile (bm x bn) and staging mode
+ * (0: general gather, 1: small-cin tap-packed K, 2: buffer-addressed whole-chunk gather)      */
+int ctsi_conv_plan_config(const ctsi_conv_plan* plan, int* bm, int* bn, int* mode);
 /* re-layout reference weights (fp32, PyTorch layout: Conv3d (cout,cin,kd,kh,kw),
  * ConvTranspose3d (cin,cout,kd,kh,kw)) into the kernel's bf16 [class][cout_pad][K] image. */
 int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* plan, const float* w_f32, void* packed,

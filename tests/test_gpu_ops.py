@@ -88,6 +88,25 @@ def test_conv_family(G, name, c1, c2, cout, dims, kind):
     assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
 
 
+@pytest.mark.parametrize("tile", ["128x128", "256x128", "256x256"])
+def test_conv_tile_variants(G, tile, monkeypatch):
+    """Every MFMA tile configuration on the same problems (incl. ragged edges, two sources, convT)."""
+    monkeypatch.setenv("CTSI_CONV_TILE", tile)
+    x1 = bf16_round(formula_input((1, 128, 5, 12, 10), 1))
+    x2 = bf16_round(formula_input((1, 64, 5, 12, 10), 2))
+    wt = bf16_round(_w((256, 192, 3, 3, 3), 3))
+    b = formula_input((256,), 4) * 0.1
+    y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=32)
+    ref = F.conv3d(torch.cat([x1, x2], 1), wt, b, padding=1)
+    assert rel_l2(y, ref) < CONV_TOL
+    rg = ref.reshape(1, 32, -1).double()
+    assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=0.5)
+    assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
+    wt_t = bf16_round(_w((128, 256, 3, 4, 4), 5, transposed=True))
+    yt, _ = G.run_conv(x1, None, wt_t, None, transposed=True, k=(3, 4, 4), s=(2, 2))
+    assert rel_l2(yt, F.conv_transpose3d(x1, wt_t, None, stride=(1, 2, 2), padding=(1, 1, 1))) < CONV_TOL
+
+
 def test_conv_fp32_strided_output_tanh_and_padded_input(G):
     # VAE decoder head: 128 -> 1 channel, tanh, written straight to fp32 NCDHW (models/vae.py:202-203)
     x = bf16_round(formula_input((1, 128, 3, 6, 5), 5))

@@ -49,8 +49,13 @@ struct ConvKParams {
     int out_mode, cout_stride, c_off, act;
     long long osn, osc, osd, osh, osw;
     int tapdelta[CTSI_MAX_TAPS];
-    int8_t od[CTSI_MAX_TAPS], oh[CTSI_MAX_TAPS], ow[CTSI_MAX_TAPS];
-    int8_t pH[4], pW[4];
+    // taps are separable: t = (a*NB + b)*NC + c with input offsets (ad[a], bh[b], cw[c]) per class
+    int NA, NB, NC;
+    int ad[4][4], bh[4][4], cw[4][4];
+    int pH[4], pW[4];
+    int tap_margin[4];  // -min(tapdelta) per class (>= 0): makes every buffer soffset non-negative
+    int ad_min[4];      // min depth tap offset per class
+    int dbg;  // timing-only ablation bits (0 in production)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -67,18 +72,22 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return start + (orig >> 3);
 }
 
-template <int WM, int WN, int TM, int TN, bool SMALL>
+template <int WM, int WN, int TM, int TN, int MODE>
 __global__ void __launch_bounds__(WM* WN * 64)
 conv_gather_mfma_kernel(const ConvKParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (buffer-resource builtins are device-only)
+    constexpr bool SMALL = (MODE == 1);
+    constexpr bool FAST = (MODE == 2);
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN, NTH = NW * 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
     static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
-    static_assert(BM * BN * 2 + NW * 32 * TN * 2 * 4 <= 2 * STAGE, "epilogue tile must fit the stages");
+    static_assert(BM * BN * 2 <= 2 * STAGE, "epilogue tile must fit the stages");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long* s_rowoff = reinterpret_cast<long long*>(smem + 2 * STAGE);
 
+    if (p.dbg & 8) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,6 +128,14 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         s_rowoff[r] = off;
     }
 
+    const int NA = p.NA, NB = p.NB, NC = p.NC;
+    int ax_d[4], ax_h[4], ax_w[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        ax_d[a] = p.ad[cls][a];
+        ax_h[a] = p.bh[cls][a];
+        ax_w[a] = p.cw[cls][a];
+    }
     // rows this lane feeds with DMA: instruction j = wave*A_INSTR + i covers rows 8j..8j+7
     int a_iv0[A_INSTR];
     unsigned long long a_mask[A_INSTR];
@@ -132,22 +149,35 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         const bool rv = (d < p.Dr) && (h < p.Hr) && (w < p.Wr);
         const int hi = h * p.sH, wi = w * p.sW;
         a_iv0[i] = ((nb * p.Di + d) * p.Hi + hi) * p.Wi + wi;
-        unsigned long long m = 0;
-        for (int t = 0; t < p.T; ++t) {
-            const int dd = d + p.od[tapbase + t], hh = hi + p.oh[tapbase + t], ww = wi + p.ow[tapbase + t];
-            const bool ok = rv && dd >= 0 && dd < p.Di && hh >= 0 && hh < p.Hi && ww >= 0 && ww < p.Wi;
-            m |= (unsigned long long)ok << t;
+        // separable validity: bit a of md says tap-depth a is inside the input, etc.
+        unsigned md = 0, mh = 0, mw = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int dd = d + ax_d[a], hh = hi + ax_h[a], ww = wi + ax_w[a];
+            md |= (unsigned)(a < NA && dd >= 0 && dd < p.Di) << a;
+            mh |= (unsigned)(a < NB && hh >= 0 && hh < p.Hi) << a;
+            mw |= (unsigned)(a < NC && ww >= 0 && ww < p.Wi) << a;
         }
+        unsigned long long row_hw = 0, m = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) row_hw |= ((mh >> b) & 1u) ? ((unsigned long long)mw << (b * NC)) : 0ull;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) m |= ((md >> a) & 1u) ? (row_hw << (a * NB * NC)) : 0ull;
+        m = rv ? m : 0ull;
         a_mask[i] = m;
     }
-    // weight rows this lane feeds
-    const bf16_t* b_ptr[B_INSTR];
+    // weight rows this lane feeds: one buffer descriptor per block, per-lane 32-bit offsets,
+    // the K-step advance (128 B) rides in the scalar offset -> no VALU work per step
+    const char* wbase = reinterpret_cast<const char*>(p.w) + ((long long)(cls * p.CoutPad + n0)) * p.Ktot * 2;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(wbase), 0, 0x7fffffff, 0x00020000);
+    unsigned b_voff[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
         const int j = wave * B_INSTR + i;
         const int r = j * 8 + (lane >> 3);
         const int q = (lane & 7) ^ ((r >> 1) & 7);
-        b_ptr[i] = p.w + ((long long)(cls * p.CoutPad + n0 + r)) * p.Ktot + q * 8;
+        b_voff[i] = (unsigned)r * (unsigned)(p.Ktot * 2) + q * 16;
     }
     __syncthreads();  // s_rowoff visible
 
@@ -162,12 +192,51 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     // fetch with a lane permute (no LDS memory access, so it never orders against the DMA).
     const int td_tab = (lane < T) ? p.tapdelta[tapbase + lane] : 0;
 
-    auto stage = [&](int s, char* buf) {
-        char* a_dst = buf + wave * (A_INSTR * 1024);
-        int td_u = 0;
-        if (!SMALL) td_u = p.tapdelta[tapbase + st_tap];
+    // fast path: per-block buffer descriptors for both sources, 32-bit per-lane offsets relative to the
+    // first input plane this tile can touch; padding / masked rows use an out-of-range offset, for
+    // which the buffer load returns zeros (no zero page, no 64-bit address arithmetic per step).
+    __amdgpu_buffer_rsrc_t a_rsrc1, a_rsrc2;
+    unsigned a_voff1[A_INSTR], a_voff2[A_INSTR];
+    int margin = 0;
+    if (FAST) {
+        int dlo = d0 + p.ad_min[cls];
+        dlo = dlo < 0 ? 0 : dlo;
+        const long long basevox = ((long long)(nb * p.Di + dlo) * p.Hi) * p.Wi;
+        margin = p.tap_margin[cls];
+        const char* b1 = x1c + (basevox - margin) * C1 * 2;
+        const char* b2 = reinterpret_cast<const char*>(p.x2) + (basevox - margin) * C2 * 2;
+        a_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b1), 0, 0x7fffffff, 0x00020000);
+        a_rsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b2), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
+            const unsigned rel = (unsigned)((long long)a_iv0[i] - basevox);
+            a_voff1[i] = rel * (unsigned)(C1 * 2) + a_q8[i] * 2;
+            a_voff2[i] = rel * (unsigned)(C2 * 2) + a_q8[i] * 2;
+        }
+    }
+
+    auto stage = [&](int s, char* buf) {
+        char* a_dst = buf + wave * (A_INSTR * 1024);
+        if (FAST) {
+            const int ch0 = st_cc * 64;
+            const bool second = ch0 >= C1;
+            const int td = p.tapdelta[tapbase + st_tap] + margin;
+            const unsigned soff = second ? (unsigned)td * (unsigned)(C2 * 2) + (unsigned)(ch0 - C1) * 2
+                                         : (unsigned)td * (unsigned)(C1 * 2) + (unsigned)ch0 * 2;
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) {
+                const bool ok = ((a_mask[i] >> st_tap) & 1ull) != 0ull;
+                const unsigned voff = ok ? (second ? a_voff2[i] : a_voff1[i]) : 0x80000000u;
+                if (second)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc2, (lptr_t)(a_dst + i * 1024), 16, voff, soff, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc1, (lptr_t)(a_dst + i * 1024), 16, voff, soff, 0, 0);
+            }
+        }
+        int td_u = 0;
+        if (!SMALL && !FAST) td_u = p.tapdelta[tapbase + st_tap];
+#pragma unroll
+        for (int i = 0; i < (FAST ? 0 : A_INSTR); ++i) {
             int tap, ch, td;
             if (SMALL) {
                 const int g = s * 8 + (a_q8[i] >> 3);
@@ -189,10 +258,8 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         }
         char* b_dst = buf + A_BYTES + wave * (B_INSTR * 1024);
 #pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            glds16(b_ptr[i], b_dst + i * 1024);
-            b_ptr[i] += CTSI_BK;
-        }
+        for (int i = 0; i < B_INSTR; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(b_dst + i * 1024), 16, b_voff[i], s * 128, 0, 0);
         if (!SMALL) {
             if (++st_tap == p.T) {
                 st_tap = 0;
@@ -218,7 +285,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     for (int kk = 0; kk < 4; ++kk) koff[kk] = (((kk * 2 + (lane >> 5)) ^ fsw) << 4) + frow;
 
     const int S = p.ksteps;
-    stage(0, smem);
+    if (!(p.dbg & 4)) stage(0, smem);
     for (int s = 0; s < S; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -243,42 +310,90 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         }
     }
     __syncthreads();  // every wave is done with the stage buffers
+    if (p.dbg & 2) return;
 
     // ---- epilogue --------------------------------------------------------------------------------
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);                          // [BM][BN]
-    float* s_cs = reinterpret_cast<float*>(smem + BM * BN * 2);                // [WM][BN][2]
+    float* s_cs = reinterpret_cast<float*>(smem + 2 * STAGE + BM * 8);         // [WM][BN][2]
     const int lhi = lane >> 5, lcol = lane & 31;
+    const bool want_sums = p.colsum != nullptr;
+    // validity of the 16*TM rows this lane's accumulators belong to (bit r of vbits[i])
+    unsigned vbits[TM];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = wn * TN * 32 + j * 32 + lcol;
-        const int co = n0 + col;
-        const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
-        float s1 = 0.0f, s2 = 0.0f;
+    for (int i = 0; i < TM; ++i) {
+        unsigned vb = 0;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            vb |= (unsigned)(s_rowoff[row] >= 0) << r;
+        }
+        vbits[i] = vb;
+    }
+    if (p.out_mode == 0 && p.act == 0) {
+        // fast path: bf16 NDHWC output staged through LDS, optional column sums
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const long long off = s_rowoff[row];
-                float v = acc[i][j][r] + bv;
-                if (p.act == 1) v = tanhf(v);
-                if (off >= 0) {
-                    s1 += v;
-                    s2 += v * v;
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * TN * 32 + j * 32 + lcol;
+            const int co = n0 + col;
+            const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                bf16_t* trow = s_tile + (wm * TM * 32 + i * 32 + 4 * lhi) * BN + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r] + bv;
+                    trow[((r & 3) + 8 * (r >> 2)) * BN] = f32_to_bf16(v);
+                    if (want_sums) {
+                        const float vm = ((vbits[i] >> r) & 1u) ? v : 0.0f;
+                        s1 += vm;
+                        s2 += vm * vm;
+                    }
                 }
-                if (p.out_mode == 0) {
-                    s_tile[row * BN + col] = f32_to_bf16(v);
-                } else if (off >= 0 && co < p.Cout) {
-                    reinterpret_cast<float*>(p.y)[off + (long long)co * p.osc] = v;
+            }
+            if (want_sums) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (lhi == 0) {
+                    s_cs[(wm * BN + col) * 2 + 0] = s1;
+                    s_cs[(wm * BN + col) * 2 + 1] = s2;
                 }
             }
         }
-        if (p.colsum != nullptr) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (lhi == 0) {
-                s_cs[(wm * BN + col) * 2 + 0] = s1;
-                s_cs[(wm * BN + col) * 2 + 1] = s2;
+    } else {
+        // generic path: activation and/or strided fp32 output (few-channel output layers)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * TN * 32 + j * 32 + lcol;
+            const int co = n0 + col;
+            const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    float v = acc[i][j][r] + bv;
+                    if (p.act == 1) v = tanhf(v);
+                    const bool valid = (vbits[i] >> r) & 1u;
+                    if (valid) {
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                    if (p.out_mode == 0) {
+                        s_tile[row * BN + col] = f32_to_bf16(v);
+                    } else if (valid && co < p.Cout) {
+                        reinterpret_cast<float*>(p.y)[s_rowoff[row] + (long long)co * p.osc] = v;
+                    }
+                }
+            }
+            if (want_sums) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (lhi == 0) {
+                    s_cs[(wm * BN + col) * 2 + 0] = s1;
+                    s_cs[(wm * BN + col) * 2 + 1] = s2;
+                }
             }
         }
     }
@@ -302,12 +417,13 @@ conv_gather_mfma_kernel(const ConvKParams p) {
             const int row = c / CPR, cc = c - row * CPR;
             const long long off = s_rowoff[row];
             const int co = n0 + cc * 8;
-            if (off >= 0 && co < p.Cout) {
+            if (off >= 0 && co < p.Cout && !(p.dbg & 1)) {
                 const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + cc * 8);
                 *reinterpret_cast<uint4*>(y + off + co) = v;
             }
         }
     }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 // ---- weight packing -----------------------------------------------------------------------------
@@ -357,7 +473,11 @@ struct ctsi_conv_plan {
     int tapk[CTSI_MAX_TAPS];
     int tapdelta[CTSI_MAX_TAPS];
     int8_t od[CTSI_MAX_TAPS], oh[CTSI_MAX_TAPS], ow[CTSI_MAX_TAPS];
+    int NA, NB, NC;
+    int ad[4][4], bh[4][4], cw[4][4];
     int8_t pH[4], pW[4];
+    int tap_margin[4], ad_min[4];
+    int fast;
     double flops;
 };
 
@@ -422,6 +542,15 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
         p->Dr = p->Do; p->Hr = p->Ho; p->Wr = p->Wo;
         p->sH = d.sh; p->sW = d.sw; p->uH = 1; p->uW = 1;
         p->pH[0] = 0; p->pW[0] = 0;
+        p->NA = d.kd; p->NB = d.kh; p->NC = d.kw;
+        if (d.kd > 3 || d.kh > 4 || d.kw > 4) {
+            free(p);
+            ctsi_set_error("ctsi_conv_plan_create: unsupported Conv3d geometry k=(%d,%d,%d)", d.kd, d.kh, d.kw);
+            return CTSI_ERR_UNSUPPORTED;
+        }
+        for (int a = 0; a < d.kd; ++a) p->ad[0][a] = a - d.pd;
+        for (int b = 0; b < d.kh; ++b) p->bh[0][b] = b - d.ph;
+        for (int c = 0; c < d.kw; ++c) p->cw[0][c] = c - d.pw;
         int t = 0;
         for (int a = 0; a < d.kd; ++a)
             for (int b = 0; b < d.kh; ++b)
@@ -456,6 +585,9 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             const int oy[2] = {0, py == 0 ? -1 : 1};
             const int kx[2] = {px == 0 ? 1 : 2, px == 0 ? 3 : 0};
             const int ox[2] = {0, px == 0 ? -1 : 1};
+            p->NA = 3; p->NB = 2; p->NC = 2;
+            for (int a = 0; a < 3; ++a) p->ad[cls][a] = 1 - a;
+            for (int b = 0; b < 2; ++b) { p->bh[cls][b] = oy[b]; p->cw[cls][b] = ox[b]; }
             int t = cls * 12;
             for (int a = 0; a < 3; ++a)
                 for (int b = 0; b < 2; ++b)
@@ -469,6 +601,15 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     }
     for (int t = 0; t < p->nclass * p->T; ++t)
         p->tapdelta[t] = (p->od[t] * d.hi + p->oh[t]) * d.wi + p->ow[t];
+    for (int c = 0; c < p->nclass; ++c) {
+        int mn = 0, dmin = 0;
+        for (int t = 0; t < p->T; ++t) {
+            if (p->tapdelta[c * p->T + t] < mn) mn = p->tapdelta[c * p->T + t];
+            if (p->od[c * p->T + t] < dmin) dmin = p->od[c * p->T + t];
+        }
+        p->tap_margin[c] = -mn;
+        p->ad_min[c] = dmin;
+    }
 
     // K walk
     if (p->Cin <= 32 && (p->Cin & (p->Cin - 1)) == 0) {
@@ -483,8 +624,28 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
         p->ksteps = p->T * p->kc_per_tap;
     }
     p->Ktot = p->ksteps * CTSI_BK;
-    p->BM = 128;
-    p->BN = d.cout <= 32 ? 32 : 128;
+    // tile selection: the bigger the tile the fewer L2->LDS bytes per flop (128x128: 64 flop/B,
+    // 256x128: 85, 256x256: 128), but the grid must still fill 256 CUs about twice over.
+    {
+        const long long rows = (long long)d.n * p->Dr * p->Hr * p->Wr * p->nclass;
+        const char* force = getenv("CTSI_CONV_TILE");  // "128x128" | "256x128" | "256x256" (tuning aid)
+        p->BM = 128;
+        p->BN = d.cout <= 32 ? 32 : 128;
+        if (d.cout > 32) {
+            const long long wg_256x256 = (rows / 256) * ceil_div(d.cout, 256);
+            const long long wg_256x128 = (rows / 256) * ceil_div(d.cout, 128);
+            if (d.cout >= 256 && d.cout % 256 == 0 && wg_256x256 >= 640) {
+                p->BM = 256; p->BN = 256;
+            } else if (wg_256x128 >= 640) {
+                p->BM = 256; p->BN = 128;
+            }
+            if (force) {
+                if (!strcmp(force, "128x128")) { p->BM = 128; p->BN = 128; }
+                if (!strcmp(force, "256x128")) { p->BM = 256; p->BN = 128; }
+                if (!strcmp(force, "256x256") && d.cout % 256 == 0) { p->BM = 256; p->BN = 256; }
+            }
+        }
+    }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
     choose_tile(p->BM, p->Dr, p->Hr, p->Wr, &p->TD, &p->TH, &p->TW);
@@ -495,6 +656,11 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     p->tilesW = ceil_div(p->Wr, p->TW);
     p->tps = p->tilesD * p->tilesH * p->tilesW;
     p->mtiles = d.n * p->tps;
+    {   // buffer-addressed fast path: whole 64-channel chunks per source and a tile halo that fits 2^31 bytes
+        const int cmax = d.c1 > d.c2 ? d.c1 : d.c2;
+        const double extent = ((double)(p->TD + 4) * d.hi * d.wi + 2.0 * d.wi + 8) * cmax * 2.0 * (p->sH > 1 ? 1 : 1);
+        p->fast = !p->small && d.c1 % 64 == 0 && d.c2 % 64 == 0 && extent < 2.0e9 && !getenv("CTSI_CONV_NO_FAST");
+    }
     if (!d.transposed)
         p->flops = 2.0 * d.n * (double)p->Do * p->Ho * p->Wo * p->Cin * d.cout * KK;
     else
@@ -519,6 +685,13 @@ extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) { return p ? p->ncl
 extern "C" int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* p) { return p ? p->tps : 0; }
 extern "C" int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* p) { return p ? p->CoutPad : 0; }
 extern "C" double ctsi_conv_plan_flops(const ctsi_conv_plan* p) { return p ? p->flops : 0.0; }
+extern "C" int ctsi_conv_plan_config(const ctsi_conv_plan* p, int* bm, int* bn, int* mode) {
+    CTSI_CHECK_ARG(p, "ctsi_conv_plan_config: null plan");
+    if (bm) *bm = p->BM;
+    if (bn) *bn = p->BN;
+    if (mode) *mode = p->small ? 1 : (p->fast ? 2 : 0);
+    return CTSI_OK;
+}
 
 // The weight tensor may carry fewer input channels than the (padded) activation tensor: the
 // VAE encoder's first conv sees a 1-channel volume stored as 8 channels (7 zero).
@@ -562,23 +735,26 @@ extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float*
 }
 
 template <int WM, int WN, int TM, int TN>
-static int launch_conv(const ConvKParams& k, bool small, int grid, hipStream_t st) {
+static int launch_conv(const ConvKParams& k, int mode, int grid, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr size_t lds = 2 * (BM * 128 + BN * 128) + BM * 8;
+    constexpr size_t lds = 2 * (BM * 128 + BN * 128) + BM * 8 + WM * BN * 8;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, false>,
+        hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, 0>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, true>,
+        hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, 1>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, 2>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if (small)
-        hipLaunchKernelGGL((conv_gather_mfma_kernel<WM, WN, TM, TN, true>), dim3(grid), dim3(WM * WN * 64),
-                           lds, st, k);
+    const dim3 g(grid), b(WM * WN * 64);
+    if (mode == 1)
+        hipLaunchKernelGGL((conv_gather_mfma_kernel<WM, WN, TM, TN, 1>), g, b, lds, st, k);
+    else if (mode == 2)
+        hipLaunchKernelGGL((conv_gather_mfma_kernel<WM, WN, TM, TN, 2>), g, b, lds, st, k);
     else
-        hipLaunchKernelGGL((conv_gather_mfma_kernel<WM, WN, TM, TN, false>), dim3(grid), dim3(WM * WN * 64),
-                           lds, st, k);
+        hipLaunchKernelGGL((conv_gather_mfma_kernel<WM, WN, TM, TN, 0>), g, b, lds, st, k);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }
@@ -616,13 +792,24 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
     k.out_mode = o->mode; k.cout_stride = o->cout_stride; k.c_off = o->c_off; k.act = o->act;
     k.osn = o->sn; k.osc = o->sc; k.osd = o->sd; k.osh = o->sh; k.osw = o->sw;
     memcpy(k.tapdelta, p->tapdelta, sizeof(k.tapdelta));
-    memcpy(k.od, p->od, sizeof(k.od));
-    memcpy(k.oh, p->oh, sizeof(k.oh));
-    memcpy(k.ow, p->ow, sizeof(k.ow));
-    memcpy(k.pH, p->pH, sizeof(k.pH));
-    memcpy(k.pW, p->pW, sizeof(k.pW));
+    k.NA = p->NA; k.NB = p->NB; k.NC = p->NC;
+    memcpy(k.ad, p->ad, sizeof(k.ad));
+    memcpy(k.bh, p->bh, sizeof(k.bh));
+    memcpy(k.cw, p->cw, sizeof(k.cw));
+    for (int c = 0; c < 4; ++c) { k.pH[c] = p->pH[c]; k.pW[c] = p->pW[c]; }
     const int grid = p->nclass * p->mtiles * p->ntiles_n;
     hipStream_t st = (hipStream_t)stream;
-    if (p->BN == 128) return launch_conv<2, 2, 2, 2>(k, p->small != 0, grid, st);
-    return launch_conv<4, 1, 1, 1>(k, p->small != 0, grid, st);
+    {   // timing-only ablation knob (wrong results): truncate the K loop to price prologue + epilogue
+        static const char* dbg = getenv("CTSI_DEBUG_KSTEPS");
+        if (dbg) k.ksteps = atoi(dbg) < k.ksteps ? atoi(dbg) : k.ksteps;
+        static const char* dbgf = getenv("CTSI_DEBUG_FLAGS");
+        k.dbg = dbgf ? atoi(dbgf) : 0;
+    }
+    memcpy(k.tap_margin, p->tap_margin, sizeof(k.tap_margin));
+    memcpy(k.ad_min, p->ad_min, sizeof(k.ad_min));
+    const int mode = p->small ? 1 : (p->fast ? 2 : 0);
+    if (p->BM == 256 && p->BN == 256) return launch_conv<2, 4, 4, 2>(k, mode, grid, st);
+    if (p->BM == 256 && p->BN == 128) return launch_conv<4, 2, 2, 2>(k, mode, grid, st);
+    if (p->BN == 128) return launch_conv<2, 2, 2, 2>(k, mode, grid, st);
+    return launch_conv<4, 1, 1, 1>(k, mode, grid, st);
 }

@@ -230,9 +230,9 @@ class Program:
             co.colsum = prog._colsum.data_ptr() if want_stats else 0
             lib.conv_fwd(plan, x1p, x2p, wp, bp, C.byref(co), sptr)
 
-        cin = x1.c + (0 if x2 is None else x2.c)
-        small = cin <= 32 and (cin & (cin - 1)) == 0
-        kernel = ("conv_mfma_128x%d%s" % (128 if cout > 32 else 32, "_smallcin" if small else ""))
+        bm, bn, mode = C.c_int(), C.c_int(), C.c_int()
+        lib.conv_plan_config(plan, C.byref(bm), C.byref(bn), C.byref(mode))
+        kernel = "conv_mfma_%dx%d_m%d" % (bm.value, bn.value, mode.value)
         self._emit(run, name, fl, kernel)
         return out_act, stats
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ctsi_conv_plan_tiles_per_sample": (_i, [_vp], False),
     "ctsi_conv_plan_cout_pad": (_i, [_vp], False),
     "ctsi_conv_plan_flops": (C.c_double, [_vp], False),
+    "ctsi_conv_plan_config": (_i, [_vp, _ip, _ip, _ip], True),
     "ctsi_conv_plan_pack_weights": (_i, [_vp, _vp, _vp, _vp], True),
     "ctsi_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ConvOut), _vp], True),
     "ctsi_gn_colsum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _ip, _vp], True),

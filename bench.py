@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU oracle leg")
+    ap.add_argument("--mode", choices=["dp", "shard"], default="dp",
+                    help="dp: one volume per GPU, no exchange (weak scaling, BASELINE config 5 style); "
+                         "shard: ONE volume depth-sharded over the GPUs with RCCL halo exchange (strong scaling, config 4)")
     return ap.parse_args()
 
 
@@ -77,6 +80,62 @@ def cpu_baseline(threads):
             "sample": "1 U-Net evaluation (fp32 torch CPU oracle) on the config-1 latent (1,8,48,48,48); "
                       f"{dt:.2f} s, {flops_192 / dt / 1e9:.0f} GFLOP/s",
             "equiv_512_steps_per_s": (flops_192 / dt) / flops_512}
+
+
+def bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist):
+    """Config 4: one 8->48 @512^2 volume, depth slab of 48/world slices per GPU, halo exchange + statistics
+    all-reduce over RCCL between kernels (eager launches: collectives are not captured)."""
+    P = importlib.import_module("video-to-video-diffusion_amd.parallel")
+    L = model.vae.latent_dim
+    d, h, w = args.depth_out, args.hw // 4, args.hw // 4
+    shape = (1, L, d, h, w)
+    gen = torch.Generator(device="cpu").manual_seed(1)          # identical volume on every rank
+    cond = torch.randn(shape, generator=gen).to(dev)
+    z_T = torch.randn(shape, generator=gen).to(dev)
+    t_desc = [int(t) for t in pkg.DDIMSampler(model.diffusion, model.unet)._get_timesteps(args.ddim_steps)]
+    total = args.warmup + args.steps
+    reps = (total + len(t_desc) - 1) // len(t_desc) + 1
+    comm = P.DistComm() if world > 1 else P.LocalComm(1)
+    spec = P.ShardSpec(rank, world, comm, d)
+    with ctx.scope():
+        prog = E.UNetProgram(ctx, model.unet, 1, spec.depth_local, h, w, max_rows=len(t_desc) * reps, shard=spec)
+        prog.add_sampler_step("ddim", False)
+        prog.load_latents(z_T, cond)
+        coef = S.ddim_coef_rows(model.diffusion.alphas_cumprod, t_desc, 0.0).repeat(reps, 1)
+        prog.set_schedule([t for _ in range(reps) for t in t_desc], coef.to(dev))
+        for _ in range(args.warmup):
+            prog.run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with ctx.scope():
+        for _ in range(args.steps):
+            prog.run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    with ctx.scope():
+        finite = bool(torch.isfinite(prog.z_ncdhw()).all().item())
+    ncomm = sum(1 for m in prog.op_meta if m[2] == "comm")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "ddim_steps_per_sec", "value": args.steps / dt, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"DDIM-{args.ddim_steps} step on ONE latent {list(shape)} depth-sharded "
+                                   f"{spec.depth_local} slices/GPU, RCCL halo exchange + GroupNorm/attention all-reduce",
+                       "parallelism": f"depth-shard{world}", "collectives_per_step": ncomm, "finite_outputs": finite},
+            "roofline": None, "cpu_baseline": None}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -107,6 +166,8 @@ def main():
     z_T = torch.randn(shape, generator=gen).to(dev)
 
     ctx = E.Ctx.get(dev)
+    if args.mode == "shard":
+        return bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist)
     sampler = pkg.DDIMSampler(model.diffusion, model.unet)
     t_desc = [int(t) for t in sampler._get_timesteps(args.ddim_steps)]          # 51 entries for 50 steps
     total = args.warmup + args.steps

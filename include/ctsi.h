@@ -75,6 +75,8 @@ typedef struct ctsi_conv_desc {
     int n, c1, c2;       /* batch, channels of source 1 and source 2 (c2 may be 0)        */
     int cout;
     int di, hi, wi;      /* input spatial size                                             */
+    int halo_d;          /* 1: the input tensor carries one halo slice below and above its own
+                            di-2 slices (depth-sharded volume); outputs cover the own slices only */
 } ctsi_conv_desc;
 
 /* epilogue description for ctsi_conv_fwd */
@@ -130,9 +132,11 @@ int ctsi_gn_colsum_tiles(int d, int h, int w);
 int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c, int c_pad, int groups,
                      int tiles_per_sample, int nclass, void* stream);
 /* y = [silu]( gn(x)*gamma+beta ) [+ tbias[n][c]] [+ residual] ; [silu] again if silu_post */
-/* tbias row used for sample i: (step_ptr ? *step_ptr : 0) * n + i  (row length tbias_stride) */
+/* tbias row used for sample i: (step_ptr ? *step_ptr : 0) * n + i  (row length tbias_stride).
+ * d_stat: depth the statistics in `sums` were accumulated over (== d on one GPU; the whole volume's
+ * depth when the tensor is one depth slab of a volume sharded across GPUs and `sums` was all-reduced). */
 int ctsi_gn_apply(const void* x_bf16, void* y_bf16, const double* sums, const float* gamma,
-                  const float* beta, int n, int c, int d, int h, int w, int groups, float eps,
+                  const float* beta, int n, int c, int d, int h, int w, int d_stat, int groups, float eps,
                   int silu_pre, const float* tbias, int tbias_stride, const int* step_ptr,
                   const void* residual_bf16, int silu_post, void* stream);
 

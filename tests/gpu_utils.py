@@ -44,7 +44,7 @@ def run_conv(x1, x2, weight, bias, *, transposed=False, k=(3, 3, 3), s=(1, 1), p
         if f32:
             # probe output dims with a throw-away plan
             desc = E.ConvDesc(int(transposed), k[0], k[1], k[2], s[0], s[1], p[0], p[1], p[2], a1.n, a1.c,
-                              0 if a2 is None else a2.c, cout, a1.d, a1.h, a1.w)
+                              0 if a2 is None else a2.c, cout, a1.d, a1.h, a1.w, 0)
             plan = C.c_void_p()
             prog.lib.conv_plan_create(C.byref(plan), C.byref(desc))
             do, ho, wo = C.c_int(), C.c_int(), C.c_int()

@@ -38,7 +38,7 @@ def test_version_and_device_probe(lib):
 
 def _plan(lib, **kw):
     d = dict(transposed=0, kd=3, kh=3, kw=3, sh=1, sw=1, pd=1, ph=1, pw=1, n=1, c1=128, c2=0, cout=128, di=48,
-             hi=128, wi=128)
+             hi=128, wi=128, halo_d=0)
     d.update(kw)
     desc = L.ConvDesc(**d)
     plan = C.c_void_p()

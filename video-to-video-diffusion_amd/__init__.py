@@ -12,3 +12,15 @@ from .diffusion import GaussianDiffusion  # noqa: F401
 from .model import VideoToVideoDiffusion  # noqa: F401
 from .sampler import DDIMSampler, DDPMSampler, EDMSampler  # noqa: F401
 from .generate import generate_batch, interpolate_videos  # noqa: F401
+from . import parallel  # noqa: F401,E402
+
+
+def enable_depth_sharding(model, group=None):
+    """Shard every following sampling run depth-wise over the ranks of `group` (torch.distributed must be
+    initialised, one process per GPU; backend "nccl" is RCCL on ROCm).  `model` is a
+    VideoToVideoDiffusion (U-Net loop and VAE decode are sharded), a UNet3D or a VideoVAE."""
+    comm = parallel.DistComm(group)
+    for m in (getattr(model, "unet", None), getattr(model, "vae", None), model):
+        if m is not None and type(m).__name__ in ("UNet3D", "SliceInterpolationVAE"):
+            m.depth_shard_comm = comm
+    return comm

@@ -53,6 +53,7 @@ struct ConvKParams {
     int NA, NB, NC;
     int ad[4][4], bh[4][4], cw[4][4];
     int pH[4], pW[4];
+    int dshift;         // rows start at input depth `dshift` (1 when the input carries depth halo slices)
     int tap_margin[4];  // -min(tapdelta) per class (>= 0): makes every buffer soffset non-negative
     int ad_min[4];      // min depth tap offset per class
     int dbg;  // timing-only ablation bits (0 in production)
@@ -148,12 +149,12 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         const int d = d0 + (r >> lTHW), h = h0 + ((r >> p.lTW) & THm), w = w0 + (r & TWm);
         const bool rv = (d < p.Dr) && (h < p.Hr) && (w < p.Wr);
         const int hi = h * p.sH, wi = w * p.sW;
-        a_iv0[i] = ((nb * p.Di + d) * p.Hi + hi) * p.Wi + wi;
+        a_iv0[i] = ((nb * p.Di + d + p.dshift) * p.Hi + hi) * p.Wi + wi;
         // separable validity: bit a of md says tap-depth a is inside the input, etc.
         unsigned md = 0, mh = 0, mw = 0;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int dd = d + ax_d[a], hh = hi + ax_h[a], ww = wi + ax_w[a];
+            const int dd = d + p.dshift + ax_d[a], hh = hi + ax_h[a], ww = wi + ax_w[a];
             md |= (unsigned)(a < NA && dd >= 0 && dd < p.Di) << a;
             mh |= (unsigned)(a < NB && hh >= 0 && hh < p.Hi) << a;
             mw |= (unsigned)(a < NC && ww >= 0 && ww < p.Wi) << a;
@@ -199,7 +200,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     unsigned a_voff1[A_INSTR], a_voff2[A_INSTR];
     int margin = 0;
     if (FAST) {
-        int dlo = d0 + p.ad_min[cls];
+        int dlo = d0 + p.dshift + p.ad_min[cls];
         dlo = dlo < 0 ? 0 : dlo;
         const long long basevox = ((long long)(nb * p.Di + dlo) * p.Hi) * p.Wi;
         margin = p.tap_margin[cls];
@@ -477,7 +478,7 @@ struct ctsi_conv_plan {
     int ad[4][4], bh[4][4], cw[4][4];
     int8_t pH[4], pW[4];
     int tap_margin[4], ad_min[4];
-    int fast;
+    int fast, dshift;
     double flops;
 };
 
@@ -525,11 +526,18 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
         return CTSI_ERR_INVALID;
     }
     p->d = d;
+    p->dshift = d.halo_d ? 1 : 0;
+    const int di_own = d.di - 2 * p->dshift;   // depth of the slab the rows cover
+    if (d.halo_d && (d.kd != 3 || d.pd != 1 || di_own < 1)) {
+        free(p);
+        ctsi_set_error("ctsi_conv_plan_create: halo_d needs kd=3, pd=1 and di >= 3");
+        return CTSI_ERR_UNSUPPORTED;
+    }
     p->Cin = d.c1 + d.c2;
     p->CinW = p->Cin;
     const int KK = d.kd * d.kh * d.kw;
     if (!d.transposed) {
-        p->Do = d.di + 2 * d.pd - d.kd + 1;
+        p->Do = di_own + 2 * d.pd - d.kd + 1;
         p->Ho = (d.hi + 2 * d.ph - d.kh) / d.sh + 1;
         p->Wo = (d.wi + 2 * d.pw - d.kw) / d.sw + 1;
         if (KK > CTSI_MAX_TAPS || p->Do <= 0 || p->Ho <= 0 || p->Wo <= 0) {
@@ -571,10 +579,10 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             ctsi_set_error("ctsi_conv_plan_create: ConvTranspose3d supports k=(3,4,4) s=(1,2,2) p=1 only");
             return CTSI_ERR_UNSUPPORTED;
         }
-        p->Do = d.di; p->Ho = d.hi * 2; p->Wo = d.wi * 2;
+        p->Do = di_own; p->Ho = d.hi * 2; p->Wo = d.wi * 2;
         p->nclass = 4;
         p->T = 12;
-        p->Dr = d.di; p->Hr = d.hi; p->Wr = d.wi;
+        p->Dr = di_own; p->Hr = d.hi; p->Wr = d.wi;
         p->sH = 1; p->sW = 1; p->uH = 2; p->uW = 2;
         for (int cls = 0; cls < 4; ++cls) {
             const int py = cls >> 1, px = cls & 1;
@@ -664,7 +672,7 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     if (!d.transposed)
         p->flops = 2.0 * d.n * (double)p->Do * p->Ho * p->Wo * p->Cin * d.cout * KK;
     else
-        p->flops = 2.0 * d.n * (double)d.di * d.hi * d.wi * p->Cin * d.cout * KK;
+        p->flops = 2.0 * d.n * (double)di_own * d.hi * d.wi * p->Cin * d.cout * KK;
     *out = p;
     return CTSI_OK;
 }
@@ -805,6 +813,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         static const char* dbgf = getenv("CTSI_DEBUG_FLAGS");
         k.dbg = dbgf ? atoi(dbgf) : 0;
     }
+    k.dshift = p->dshift;
     memcpy(k.tap_margin, p->tap_margin, sizeof(k.tap_margin));
     memcpy(k.ad_min, p->ad_min, sizeof(k.ad_min));
     const int mode = p->small ? 1 : (p->fast ? 2 : 0);

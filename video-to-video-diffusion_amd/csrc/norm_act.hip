@@ -148,7 +148,7 @@ extern "C" int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c,
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const double* __restrict__ sums,
                 const float* __restrict__ gamma, const float* __restrict__ beta, int c, long long vox,
-                int groups, float eps, int silu_pre, const float* __restrict__ tbias, int tbias_stride,
+                long long vox_stat, int groups, float eps, int silu_pre, const float* __restrict__ tbias, int tbias_stride,
                 const int* __restrict__ step_ptr, int n_total, const bf16_t* __restrict__ residual,
                 int silu_post) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -157,7 +157,7 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const doub
     float* s_tb = s_shift + c;
     const int nb = blockIdx.y, tid = threadIdx.x;
     const int cpg = c / groups;
-    const double cnt = (double)cpg * (double)vox;
+    const double cnt = (double)cpg * (double)vox_stat;
     long long trow = nb;
     if (step_ptr) trow += (long long)(*step_ptr) * n_total;
     for (int ch = tid; ch < c; ch += 256) {
@@ -198,11 +198,12 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const doub
 }
 
 extern "C" int ctsi_gn_apply(const void* x, void* y, const double* sums, const float* gamma, const float* beta,
-                             int n, int c, int d, int h, int w, int groups, float eps, int silu_pre,
+                             int n, int c, int d, int h, int w, int d_stat, int groups, float eps, int silu_pre,
                              const float* tbias, int tbias_stride, const int* step_ptr,
                              const void* residual, int silu_post, void* stream) {
     CTSI_CHECK_ARG(x && y && sums && gamma && beta, "ctsi_gn_apply: null argument");
     CTSI_CHECK_ARG(c % 8 == 0 && groups > 0 && c % groups == 0, "ctsi_gn_apply: bad c=%d groups=%d", c, groups);
+    CTSI_CHECK_ARG(d_stat >= d, "ctsi_gn_apply: d_stat=%d < d=%d", d_stat, d);
     const long long vox = (long long)d * h * w;
     const long long total = vox * (c / 8);
     long long blocks = (total + 256 * 8 - 1) / (256 * 8);
@@ -210,7 +211,8 @@ extern "C" int ctsi_gn_apply(const void* x, void* y, const double* sums, const f
     if (blocks < 1) blocks = 1;
     const size_t lds = (size_t)c * 3 * sizeof(float);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, n), dim3(256), lds, (hipStream_t)stream,
-                       (const bf16_t*)x, (bf16_t*)y, sums, gamma, beta, c, vox, groups, eps, silu_pre, tbias,
+                       (const bf16_t*)x, (bf16_t*)y, sums, gamma, beta, c, vox, (long long)d_stat * h * w, groups, eps,
+                       silu_pre, tbias,
                        tbias_stride, step_ptr, n, (const bf16_t*)residual, silu_post);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;

@@ -89,15 +89,32 @@ class _Pool:
 
 
 class Act:
-    """A bf16 NDHWC activation buffer with its logical shape."""
-    __slots__ = ("t", "n", "c", "d", "h", "w")
+    """A bf16 NDHWC activation buffer with its logical shape.  In depth-sharded programs (`halo` = 1)
+    the buffer holds d + 2 slices: one halo slice below and above the rank's own d slices."""
+    __slots__ = ("t", "n", "c", "d", "h", "w", "halo", "dirty")
 
-    def __init__(self, t, n, c, d, h, w):
+    def __init__(self, t, n, c, d, h, w, halo=0):
         self.t, self.n, self.c, self.d, self.h, self.w = t, n, c, d, h, w
+        self.halo = halo
+        self.dirty = True  # halo slices stale (they are refreshed lazily, right before a depth-3 conv)
 
     @property
     def vox(self):
         return self.d * self.h * self.w
+
+    @property
+    def slice_elems(self):
+        return self.h * self.w * self.c
+
+    @property
+    def ip(self) -> C.c_void_p:
+        """pointer to the first own (interior) slice"""
+        return C.c_void_p(self.t.data_ptr() + self.halo * self.slice_elems * 2)
+
+    @property
+    def fp(self) -> C.c_void_p:
+        """pointer to the whole buffer (lower halo slice first)"""
+        return C.c_void_p(self.t.data_ptr())
 
 
 class Program:
@@ -122,14 +139,44 @@ class Program:
         self.graph = None
         self._params: List[torch.Tensor] = []
         self._versions: Tuple[int, ...] = ()
+        self.shard = None  # parallel.ShardSpec for depth-sharded programs
 
     def _emit(self, fn: Callable[[], None], name: str = "op", flops: float = 0.0, kernel: str = ""):
         self.ops.append(fn)
         self.op_meta.append((name, flops, kernel))
 
     # ---- buffers -------------------------------------------------------------------------------------
-    def act(self, n, c, d, h, w) -> Act:
-        return Act(self.pool.get(n * c * d * h * w, torch.bfloat16), n, c, d, h, w)
+    def act(self, n, c, d, h, w, halo: Optional[int] = None) -> Act:
+        if halo is None:
+            halo = 1 if self.shard is not None else 0
+        return Act(self.pool.get(n * c * (d + 2 * halo) * h * w, torch.bfloat16), n, c, d, h, w, halo)
+
+    # ---- depth-sharding collectives (no-ops in single-GPU programs) -----------------------------------
+    def halo_exchange(self, a: Act):
+        """Refresh a's two halo slices from the depth neighbours (zeros at the volume's ends)."""
+        if self.shard is None or not a.halo or not a.dirty:
+            return
+        a.dirty = False
+        se = a.slice_elems
+        buf, d = a.t, a.d
+        views = dict(lo_halo=buf[0:se], lo_own=buf[se:2 * se], hi_own=buf[d * se:(d + 1) * se],
+                     hi_halo=buf[(d + 1) * se:(d + 2) * se])
+        spec, stream = self.shard, self.ctx.stream
+
+        def run():
+            spec.comm.exchange(spec.rank, views["lo_own"], views["hi_own"], views["lo_halo"], views["hi_halo"])
+
+        self._emit(run, "halo.exchange", 0.0, "comm")
+
+    def all_reduce(self, t: torch.Tensor, name: str):
+        if self.shard is None:
+            return
+        spec = self.shard
+
+        def run():
+            spec.comm.all_reduce(spec.rank, t)
+
+        self._emit(run, name, 0.0, "comm")
 
     def release(self, a: Act):
         self.pool.put(a.t)
@@ -173,8 +220,16 @@ class Program:
         """Emit one convolution.  weight_fn/bias_fn return the *current* fp32 parameter tensors
         (possibly derived, e.g. scaled or pre-multiplied).  Returns (out_act, stats_handle)."""
         lib = self.lib
+        deep = k[0] > 1 and x1.halo == 1   # depth taps read the halo slices: "valid" conv along depth
+        if x1.halo and x1.n != 1:
+            raise CtsiError("depth-sharded programs support one volume per rank")
+        if deep:
+            self.halo_exchange(x1)
+            if x2 is not None:
+                self.halo_exchange(x2)
+        di = x1.d + 2 if deep else x1.d
         desc = ConvDesc(int(transposed), k[0], k[1], k[2], s[0], s[1], p[0], p[1], p[2], x1.n, x1.c,
-                        0 if x2 is None else x2.c, cout, x1.d, x1.h, x1.w)
+                        0 if x2 is None else x2.c, cout, di, x1.h, x1.w, 1 if deep else 0)
         plan = C.c_void_p()
         lib.conv_plan_create(C.byref(plan), C.byref(desc))
         self.plans.append(plan)
@@ -215,15 +270,18 @@ class Program:
             out_act = None
         else:
             if out is None:
-                out = self.act(x1.n, cout, do, ho, wo)
-            co.y = out.t.data_ptr()
+                out = self.act(x1.n, cout, do, ho, wo, halo=x1.halo)
+            out.dirty = True
+            co.y = out.ip.value
             co.mode = 0
             co.cout_stride = out.c
             co.c_off = 0
             out_act = out
         co.act = act
         self.keep.append(co)
-        x1p, x2p, wp, bp = _ptr(x1.t), _ptr(None if x2 is None else x2.t), _ptr(packed), _ptr(bias)
+        x1p = x1.fp if deep else x1.ip
+        x2p = C.c_void_p(0) if x2 is None else (x2.fp if deep else x2.ip)
+        wp, bp = _ptr(packed), _ptr(bias)
         prog = self
 
         def run():
@@ -254,13 +312,23 @@ class Program:
                             groups, tps, nclass, sptr)
 
         self._emit(run, "gn.finalize")
+        if self.shard is not None:
+            nvals = x.n * groups * 2
+            holder = {}
+
+            def run_ar():
+                if "v" not in holder:
+                    holder["v"] = prog._gn_sums[slot:slot + nvals]
+                prog.shard.comm.all_reduce(prog.shard.rank, holder["v"])
+
+            self._emit(run_ar, "gn.allreduce", 0.0, "comm")
         return slot
 
     def gn_colsum(self, x: Act) -> dict:
         lib, sptr, prog = self.lib, self.ctx.sptr, self
         tps = lib.gn_colsum_tiles(x.d, x.h, x.w)
         self._colsum_need = max(self._colsum_need, 2 * x.n * tps * x.c)
-        xp = _ptr(x.t)
+        xp = x.ip
         n, c, d, h, w = x.n, x.c, x.d, x.h, x.w
 
         def run():
@@ -277,16 +345,18 @@ class Program:
         beta = self.dev_f32(lambda: gn.bias)
         self.track(gn.weight, gn.bias)
         if out is None:
-            out = self.act(x.n, x.c, x.d, x.h, x.w)
-        xp, yp, gp, bp = _ptr(x.t), _ptr(out.t), _ptr(gamma), _ptr(beta)
+            out = self.act(x.n, x.c, x.d, x.h, x.w, halo=x.halo)
+        out.dirty = True
+        xp, yp, gp, bp = x.ip, out.ip, _ptr(gamma), _ptr(beta)
         tbp = C.c_void_p(0 if tbias is None else tbias.data_ptr() + tbias_off * 4)
         stp = _ptr(step_ptr)
-        rp = _ptr(None if residual is None else residual.t)
+        rp = C.c_void_p(0) if residual is None else residual.ip
         n, c, d, h, w, groups, eps = x.n, x.c, x.d, x.h, x.w, gn.num_groups, float(gn.eps)
+        d_stat = d * (self.shard.world if (self.shard is not None and x.halo) else 1)  # statistics span all ranks
 
         def run():
-            lib.gn_apply(xp, yp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, n, c, d, h, w, groups,
-                         eps, int(silu_pre), tbp, tbias_stride, stp, rp, int(silu_post), sptr)
+            lib.gn_apply(xp, yp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, n, c, d, h, w, d_stat,
+                         groups, eps, int(silu_pre), tbp, tbias_stride, stp, rp, int(silu_post), sptr)
 
         self._emit(run, "gn.apply")
         return out
@@ -328,21 +398,25 @@ class Program:
         tps = lib.attn_depthsum_tiles(c, h, w)
         self._colsum_need = max(self._colsum_need, 2 * n * tps * c)
         depthsum = self.pool.get(n * h * w * c, torch.float32)
-        xp, dsp = _ptr(x.t), _ptr(depthsum)
+        xp, dsp = x.ip, _ptr(depthsum)
+        world = self.shard.world if (self.shard is not None and x.halo) else 1
+        d_all = d * world
 
         def run_ds():
             lib.attn_depthsum(xp, dsp, _ptr(prog._colsum), n, c, d, h, w, sptr)
 
         self._emit(run_ds, "attn.depthsum")
+        if world > 1:
+            self.all_reduce(depthsum, "attn.allreduce")
         slot = self.gn_finalize(x, m.norm.num_groups, dict(tps=tps, cpad=c, nclass=1))
         gamma = self.dev_f32(lambda: m.norm.weight)
         beta = self.dev_f32(lambda: m.norm.bias)
-        xs = self.act(n, c, 1, h, w)
+        xs = self.act(n, c, 1, h, w, halo=0)
         groups, eps = m.norm.num_groups, float(m.norm.eps)
         gp, bp, xsp = _ptr(gamma), _ptr(beta), _ptr(xs.t)
 
         def run_ns():
-            lib.attn_normsum(dsp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, xsp, n, c, d, h, w,
+            lib.attn_normsum(dsp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, xsp, n, c, d_all, h, w,
                              groups, eps, sptr)
 
         self._emit(run_ns, "attn.normsum")
@@ -357,7 +431,7 @@ class Program:
 
         def bpv():
             wp = m.proj_out.weight[:, :, 0, 0, 0].double()
-            return (float(d) * (wp @ m.qkv.bias[2 * c:3 * c].double()) + m.proj_out.bias.double()).float()
+            return (float(d_all) * (wp @ m.qkv.bias[2 * c:3 * c].double()) + m.proj_out.bias.double()).float()
 
         pterm, _ = self.conv("attn.pv", wpv, bpv, xs, None, k=(1, 1, 1), p=(0, 0, 0), cout=c)
         self.pool.put(depthsum)
@@ -369,16 +443,18 @@ class Program:
             qk, _ = self.conv("attn.qk", lambda: m.qkv.weight[:2 * c], lambda: m.qkv.bias[:2 * c], xn, None,
                               k=(1, 1, 1), p=(0, 0, 0), cout=2 * c)
             self.release(xn)
+            if world > 1:
+                raise CtsiError("exact-mode attention needs every key on one rank; use the fast mode when sharding")
             rowsum = self.pool.get(n * d * h * w * heads, torch.float32)
-            qkp, rsp = _ptr(qk.t), _ptr(rowsum)
+            qkp, rsp = qk.ip, _ptr(rowsum)
 
             def run_rs():
                 lib.attn_softmax_rowsum(qkp, rsp, n, c, d, h, w, heads, sptr)
 
             self._emit(run_rs, "attn.softmax_rowsum")
             self.release(qk)
-        out = self.act(n, c, d, h, w)
-        pp, op_, rsp2 = _ptr(pterm.t), _ptr(out.t), _ptr(rowsum)
+        out = self.act(n, c, d, h, w, halo=x.halo)
+        pp, op_, rsp2 = pterm.ip, out.ip, _ptr(rowsum)
 
         def run_ba():
             lib.attn_broadcast_add(xp, pp, rsp2, heads, op_, n, c, d, h, w, sptr)
@@ -465,8 +541,14 @@ class UNetProgram(Program):
     """One U-Net evaluation (models/unet3d.py:357-413) at a fixed latent shape, followed optionally by
     a sampler update; `step_ptr` selects the timestep row, so one captured graph serves all steps."""
 
-    def __init__(self, ctx: Ctx, unet, n: int, d: int, h: int, w: int, max_rows: int, attention_mode="fast"):
+    def __init__(self, ctx: Ctx, unet, n: int, d: int, h: int, w: int, max_rows: int, attention_mode="fast",
+                 shard=None):
+        """`d` is the depth this program owns: the whole volume on one GPU, or the rank's slab of
+        `shard.depth_total // shard.world` slices when `shard` (parallel.ShardSpec) is given."""
         super().__init__(ctx)
+        self.shard = shard
+        if shard is not None and n != 1:
+            raise CtsiError("depth-sharded programs support one volume per rank")
         self.unet = unet
         self.n, self.d, self.h, self.w = n, d, h, w
         L = unet.latent_dim
@@ -474,7 +556,9 @@ class UNetProgram(Program):
         dev = ctx.device
         self.attention_mode = attention_mode
         self.max_rows = max_rows
-        self.xin = Act(self.persistent((n * d * h * w * 2 * L,), torch.bfloat16, zero=True), n, 2 * L, d, h, w)
+        halo = 0 if shard is None else 1
+        self.xin = Act(self.persistent((n * (d + 2 * halo) * h * w * 2 * L,), torch.bfloat16, zero=True), n, 2 * L, d,
+                       h, w, halo)
         self.eps = self.persistent((n, d, h, w, L), torch.float32)
         self.z = self.persistent((n, d, h, w, L), torch.float32, zero=True)
         self.step_ptr = self.persistent((1,), torch.int32, zero=True)
@@ -563,16 +647,19 @@ class UNetProgram(Program):
 
     # -- inputs / schedule --
     def load_latents(self, z_ncdhw: Optional[torch.Tensor], cond_ncdhw: Optional[torch.Tensor]):
+        """Take (this rank's depth slab of) the fp32 NCDHW latent / conditioning into the engine layout."""
         lib, sptr = self.lib, self.ctx.sptr
         n, L, d, h, w = self.n, self.L, self.d, self.h, self.w
+        lo = 0 if self.shard is None else self.shard.rank * d
         if z_ncdhw is not None:
-            z = z_ncdhw.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+            z = z_ncdhw.detach()[:, :, lo:lo + d].to(device=self.ctx.device, dtype=torch.float32).contiguous()
             lib.ncdhw_f32_to_ndhwc_f32(_ptr(z), _ptr(self.z), n, L, d, h, w, sptr)
-            lib.ncdhw_f32_to_ndhwc_bf16(_ptr(z), _ptr(self.xin.t), n, L, d, h, w, 2 * L, 0, sptr)
+            lib.ncdhw_f32_to_ndhwc_bf16(_ptr(z), self.xin.ip, n, L, d, h, w, 2 * L, 0, sptr)
             z.record_stream(self.ctx.stream)
+            self.xin.dirty = True
         if cond_ncdhw is not None:
-            cnd = cond_ncdhw.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
-            lib.ncdhw_f32_to_ndhwc_bf16(_ptr(cnd), _ptr(self.xin.t), n, L, d, h, w, 2 * L, L, sptr)
+            cnd = cond_ncdhw.detach()[:, :, lo:lo + d].to(device=self.ctx.device, dtype=torch.float32).contiguous()
+            lib.ncdhw_f32_to_ndhwc_bf16(_ptr(cnd), self.xin.ip, n, L, d, h, w, 2 * L, L, sptr)
             cnd.record_stream(self.ctx.stream)
 
     def set_schedule(self, t_rows: Sequence[int], coef_rows: Optional[torch.Tensor] = None):
@@ -599,6 +686,8 @@ class UNetProgram(Program):
         return out
 
     def z_ncdhw(self) -> torch.Tensor:
+        """The sampler state as fp32 NCDHW (the rank's slab only when depth-sharded; gather with
+        shard.comm.gather_depth)."""
         out = torch.empty((self.n, self.L, self.d, self.h, self.w), dtype=torch.float32, device=self.ctx.device)
         self.lib.ndhwc_f32_to_ncdhw_f32(_ptr(self.z), _ptr(out), self.n, self.L, self.d, self.h, self.w,
                                         self.ctx.sptr)
@@ -611,11 +700,14 @@ class UNetProgram(Program):
         if with_noise and self.noise is None:
             self.noise = self.persistent((n, L, d, h, w), torch.float32, zero=True)
         fn = lib.ddim_step if kind == "ddim" else lib.ddpm_step
-        zp, ep, xp, cp, sp = _ptr(self.z), _ptr(self.eps), _ptr(self.xin.t), _ptr(self.coef), _ptr(self.step_ptr)
+        zp, ep, xp, cp, sp = _ptr(self.z), _ptr(self.eps), self.xin.ip, _ptr(self.coef), _ptr(self.step_ptr)
         npz = _ptr(self.noise if with_noise else None)
+
+        xin = self.xin
 
         def run_step():
             fn(zp, ep, npz, xp, 2 * L, 0, cp, sp, n, L, d, h, w, sptr)
+            xin.dirty = True
 
         def run_adv():
             lib.step_advance(sp, sptr)
@@ -710,17 +802,21 @@ class VAEEncodeProgram(Program):
 
 
 class VAEDecodeProgram(VAEEncodeProgram):
-    """VideoDecoder.forward + unscaling (models/vae.py:190-204, 249-260) at a fixed latent shape."""
+    """VideoDecoder.forward + unscaling (models/vae.py:190-204, 249-260) at a fixed latent shape.
+    With `shard` the program decodes this rank's depth slab (d = local depth); halos are exchanged before
+    every depth-3 conv and the GroupNorm statistics are all-reduced, as in the U-Net."""
 
-    def __init__(self, ctx: Ctx, vae, n, d, h, w):
+    def __init__(self, ctx: Ctx, vae, n, d, h, w, shard=None):
         Program.__init__(self, ctx)
+        self.shard = shard
         dec = vae.decoder
         self.n, self.d, self.h, self.w = n, d, h, w
         L = vae.latent_dim
         self.L, self.L_pad = L, _pad8(L)
         self.track(*[p for p in dec.parameters()])
-        self.zin = Act(self.persistent((n * d * h * w * self.L_pad,), torch.bfloat16, zero=True), n, self.L_pad,
-                       d, h, w)
+        halo = 0 if shard is None else 1
+        self.zin = Act(self.persistent((n * (d + 2 * halo) * h * w * self.L_pad,), torch.bfloat16, zero=True), n,
+                       self.L_pad, d, h, w, halo)
         self.zero_gn_op()
         inv = lambda: 1.0 / float(vae.scaling_factor)
         x, _ = self.conv("dec.post_quant", lambda: dec.post_quant_conv.weight * inv(),
@@ -745,15 +841,21 @@ class VAEDecodeProgram(VAEEncodeProgram):
         self.release(x)
         self.finalize_layout()
 
-    def __call__(self, z: torch.Tensor) -> torch.Tensor:
+    def load(self, z: torch.Tensor):
         lib, sptr = self.lib, self.ctx.sptr
         self.ensure_fresh()
-        zz = z.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
-        lib.ncdhw_f32_to_ndhwc_bf16(_ptr(zz), _ptr(self.zin.t), self.n, self.L, self.d, self.h, self.w,
-                                    self.L_pad, 0, sptr)
+        lo = 0 if self.shard is None else self.shard.rank * self.d
+        zz = z.detach()[:, :, lo:lo + self.d].to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        lib.ncdhw_f32_to_ndhwc_bf16(_ptr(zz), self.zin.ip, self.n, self.L, self.d, self.h, self.w, self.L_pad, 0, sptr)
         zz.record_stream(self.ctx.stream)
-        self.launch()
-        return self.out.clone()
+
+    def __call__(self, z: torch.Tensor) -> torch.Tensor:
+        self.load(z)
+        if self.shard is None:
+            self.launch()
+            return self.out.clone()
+        self.run()
+        return self.shard.comm.gather_depth(self.shard.rank, self.out)
 
 
 # ==========================================================================================================

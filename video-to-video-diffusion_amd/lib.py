@@ -30,6 +30,7 @@ class ConvDesc(C.Structure):
         ("n", C.c_int), ("c1", C.c_int), ("c2", C.c_int),
         ("cout", C.c_int),
         ("di", C.c_int), ("hi", C.c_int), ("wi", C.c_int),
+        ("halo_d", C.c_int),
     ]
 
 
@@ -73,7 +74,7 @@ SIGNATURES = {
     "ctsi_gn_colsum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _ip, _vp], True),
     "ctsi_gn_colsum_tiles": (_i, [_i, _i, _i], False),
     "ctsi_gn_finalize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], True),
-    "ctsi_gn_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp,
+    "ctsi_gn_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp,
                            _i, _vp], True),
     "ctsi_attn_depthsum": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_attn_depthsum_tiles": (_i, [_i, _i, _i], False),

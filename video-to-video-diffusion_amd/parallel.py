@@ -1,0 +1,169 @@
+"""Multi-GPU execution of the sampling path (one process per GPU, torch.distributed over RCCL/xGMI).
+
+Two ways the path shards:
+
+* data parallel — volumes (or sliding-window patches) are independent: every rank runs the
+  single-GPU engine on its own units, nothing is exchanged while computing, results are gathered
+  at the end (`shard_units`, `gather_units`).  This is what `bench.py --gpus N` measures.
+
+* depth sharding — one volume's depth D is cut into `world` equal slabs.  D is never resampled inside
+  the U-Net / VAE and every non-pointwise conv has k_D = 3, stride 1, pad 1, so a slab plus one halo
+  slice per side is exact.  Exchanges per network evaluation:
+      - before each depth-3 conv: neighbour send/recv of the two boundary slices (zeros at the ends),
+      - after each GroupNorm statistics pass: all-reduce of (sum, sumsq) per (sample, group), fp64,
+      - TemporalAttention: all-reduce of the depth-sum S = sum_d x  (n, h, w, c) fp32
+        (the reference's einsum makes attention a depth *sum*, so no all-to-all is needed).
+  The engine emits these as `comm` ops inside the program (engine.Program.halo_exchange/all_reduce).
+
+`DistComm` binds them to torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" for the CPU tests);
+`LocalComm` runs `world` virtual ranks inside one process in lock-step so the sharded arithmetic can be
+checked against the unsharded engine on a single GPU.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from .lib import CtsiError
+
+
+# ---- data parallel helpers --------------------------------------------------------------------------------
+def shard_units(num_units: int, rank: int, world: int) -> range:
+    """Contiguous, balanced partition of independent units (volumes, patches): rank r owns
+    [r*q + min(r, rem), ...) — the first `rem` ranks take one extra unit."""
+    q, rem = divmod(num_units, world)
+    start = rank * q + min(rank, rem)
+    return range(start, start + q + (1 if rank < rem else 0))
+
+
+def gather_units(local: torch.Tensor, counts: Sequence[int], group=None) -> torch.Tensor:
+    """All-gather ragged batches along dim 0 (each rank contributes counts[rank] items)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    cmax = max(counts)
+    pad = torch.zeros((cmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad, group=group)
+    return torch.cat([o[:c] for o, c in zip(outs, counts)], dim=0)
+
+
+def depth_slab(depth: int, rank: int, world: int) -> range:
+    if depth % world != 0:
+        raise CtsiError(f"depth sharding needs depth ({depth}) divisible by the number of ranks ({world})")
+    q = depth // world
+    return range(rank * q, (rank + 1) * q)
+
+
+# ---- communicators ---------------------------------------------------------------------------------------------
+class DistComm:
+    """Depth-sharding collectives over torch.distributed (RCCL on GPUs, gloo on CPU tensors)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise CtsiError("DistComm needs an initialised torch.distributed process group")
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    @staticmethod
+    def _raw(t: torch.Tensor) -> torch.Tensor:
+        return t.view(torch.int16) if t.dtype == torch.bfloat16 else t
+
+    def exchange(self, rank: int, lo_own, hi_own, lo_halo, hi_halo):
+        """lo_halo <- rank-1's hi_own, hi_halo <- rank+1's lo_own; zeros at the volume's two ends."""
+        dist, ops = self.dist, []
+        if rank > 0:
+            ops.append(dist.P2POp(dist.isend, self._raw(lo_own), rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, self._raw(lo_halo), rank - 1, self.group))
+        else:
+            lo_halo.zero_()
+        if rank < self.world - 1:
+            ops.append(dist.P2POp(dist.isend, self._raw(hi_own), rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, self._raw(hi_halo), rank + 1, self.group))
+        else:
+            hi_halo.zero_()
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def all_reduce(self, rank: int, t: torch.Tensor):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def gather_depth(self, rank: int, slab: torch.Tensor) -> torch.Tensor:
+        outs = [torch.empty_like(slab) for _ in range(self.world)]
+        self.dist.all_gather(outs, slab.contiguous(), group=self.group)
+        return torch.cat(outs, dim=2)
+
+
+class LocalComm:
+    """`world` virtual ranks in one process, driven in lock-step (op i of rank 0, 1, ... then op i+1):
+    each collective call parks its tensors; the last rank to arrive performs the exchange for all."""
+
+    def __init__(self, world: int):
+        self.world = world
+        self._pending: List[tuple] = []
+
+    def _arrive(self, item) -> Optional[List[tuple]]:
+        self._pending.append(item)
+        if len(self._pending) < self.world:
+            return None
+        items, self._pending = sorted(self._pending, key=lambda it: it[0]), []
+        return items
+
+    def exchange(self, rank: int, lo_own, hi_own, lo_halo, hi_halo):
+        items = self._arrive((rank, lo_own, hi_own, lo_halo, hi_halo))
+        if items is None:
+            return
+        for r, (_, lo, hi, lo_h, hi_h) in enumerate(items):
+            if r > 0:
+                lo_h.copy_(items[r - 1][2])
+            else:
+                lo_h.zero_()
+            if r < self.world - 1:
+                hi_h.copy_(items[r + 1][1])
+            else:
+                hi_h.zero_()
+
+    def all_reduce(self, rank: int, t: torch.Tensor):
+        items = self._arrive((rank, t))
+        if items is None:
+            return
+        total = items[0][1].clone()
+        for _, other in items[1:]:
+            total += other
+        for _, dst in items:
+            dst.copy_(total)
+
+    def gather_depth(self, rank: int, slab: torch.Tensor):
+        items = self._arrive((rank, slab))
+        if items is None:
+            return None
+        return torch.cat([s for _, s in items], dim=2)
+
+
+@dataclass
+class ShardSpec:
+    rank: int
+    world: int
+    comm: object          # DistComm | LocalComm
+    depth_total: int
+
+    @property
+    def depth_local(self) -> int:
+        return len(depth_slab(self.depth_total, self.rank, self.world))
+
+
+def run_lockstep(programs: Sequence, launches: int = 1):
+    """Drive the programs of all virtual ranks op by op (LocalComm)."""
+    nops = len(programs[0].ops)
+    if any(len(p.ops) != nops for p in programs):
+        raise CtsiError("virtual ranks built different programs")
+    for _ in range(launches):
+        for i in range(nops):
+            for p in programs:
+                p.ops[i]()

@@ -51,6 +51,42 @@ def ddim_coef_rows(alphas_cumprod: torch.Tensor, timesteps: Sequence[int], eta: 
     return rows
 
 
+def run_sampler_sharded(diffusion, unet, shape, conditioning, ctx, z0, *, kind, t_desc, eta, noise_fn, comm,
+                        trajectory=None):
+    """Depth-sharded reverse loop: this process owns depth slab `comm.rank` of the volume
+    (parallel.DistComm over RCCL).  Every rank passes the full conditioning / initial noise and gets
+    the full result back (all-gather along depth)."""
+    from .engine import cached_program
+    from .parallel import ShardSpec
+    n, L, d, h, w = [int(v) for v in shape]
+    spec = ShardSpec(comm.rank, comm.world, comm, d)
+    dl = spec.depth_local
+    with_noise = (kind == "ddpm") or eta > 0
+    steps = len(t_desc)
+    with ctx.scope():
+        key = ("sampler-shard", ctx.device.index, n, d, h, w, comm.rank, comm.world, kind, with_noise)
+
+        def build():
+            prog = UNetProgram(ctx, unet, n, dl, h, w, (diffusion.timesteps + 1) * n, "fast", shard=spec)
+            prog.add_sampler_step(kind, with_noise)
+            return prog
+
+        prog = cached_program(unet, key, build)
+        prog.load_latents(z0, conditioning)
+        coef = (ddim_coef_rows(diffusion.alphas_cumprod, t_desc, eta) if kind == "ddim"
+                else diffusion.ddpm_coef_rows(t_desc))
+        prog.set_schedule([int(t) for t in t_desc for _ in range(n)], coef.to(ctx.device))
+        lo = comm.rank * dl
+        for i in range(steps):
+            if with_noise:
+                full = noise_fn(i, tuple(shape)) if noise_fn is not None else torch.randn(tuple(shape), device=ctx.device)
+                prog.noise.copy_(full[:, :, lo:lo + dl].to(ctx.device, torch.float32))
+            prog.run()
+            if trajectory is not None:
+                trajectory.append(comm.gather_depth(comm.rank, prog.z_ncdhw()))
+        return comm.gather_depth(comm.rank, prog.z_ncdhw())
+
+
 def run_sampler(diffusion, model, shape, conditioning, device, *, kind: str, t_desc: Sequence[int],
                 progress: bool, eta: float = 0.0, noise_fn=None, z_init: Optional[torch.Tensor] = None,
                 trajectory: Optional[list] = None):
@@ -69,6 +105,10 @@ def run_sampler(diffusion, model, shape, conditioning, device, *, kind: str, t_d
         z0 = noise_fn(-1, tuple(shape)).to(ctx.device)
     else:
         z0 = torch.randn(tuple(shape), device=ctx.device)
+    comm = getattr(unet, "depth_shard_comm", None)
+    if comm is not None and comm.world > 1:
+        return run_sampler_sharded(diffusion, unet, shape, conditioning, ctx, z0, kind=kind, t_desc=t_desc, eta=eta,
+                                   noise_fn=noise_fn, comm=comm, trajectory=trajectory)
     with ctx.scope():
         key = ("sampler", ctx.device.index, n, d, h, w, max_rows, kind, with_noise, unet.attention_mode)
         from .engine import cached_program

@@ -122,9 +122,17 @@ class SliceInterpolationVAE(nn.Module):
         if c != self.latent_dim:
             raise ValueError(f"decode expects {self.latent_dim} latent channels, got {c}")
         ctx = Ctx.get(z.device)
+        comm = getattr(self, "depth_shard_comm", None)
         with ctx.scope():
-            key = ("dec", ctx.device.index, n, d, h, w, float(self.scaling_factor))
-            prog = cached_program(self, key, lambda: VAEDecodeProgram(ctx, self, n, d, h, w))
+            if comm is not None and comm.world > 1:
+                from .parallel import ShardSpec
+                spec = ShardSpec(comm.rank, comm.world, comm, d)
+                key = ("dec-shard", ctx.device.index, n, d, h, w, comm.rank, comm.world, float(self.scaling_factor))
+                prog = cached_program(self, key, lambda: VAEDecodeProgram(ctx, self, n, spec.depth_local, h, w,
+                                                                           shard=spec))
+            else:
+                key = ("dec", ctx.device.index, n, d, h, w, float(self.scaling_factor))
+                prog = cached_program(self, key, lambda: VAEDecodeProgram(ctx, self, n, d, h, w))
             return prog(z)
 
     def encode_with_posterior(self, x):

@@ -107,6 +107,44 @@ def test_conv_tile_variants(G, tile, monkeypatch):
     assert rel_l2(yt, F.conv_transpose3d(x1, wt_t, None, stride=(1, 2, 2), padding=(1, 1, 1))) < CONV_TOL
 
 
+HALO3_CASES = [
+    # name, c1, c2, cout, (n,d,h,w)
+    ("aligned_64_128", 64, 0, 128, (1, 4, 4, 16)),
+    ("multi_tile_128_128", 128, 0, 128, (1, 8, 8, 32)),
+    ("ragged_edges_batch2", 64, 0, 64, (2, 5, 7, 21)),
+    ("concat_64+32_cout256", 64, 32, 256, (1, 3, 6, 18)),
+    ("concat_256+128", 256, 128, 128, (1, 4, 5, 16)),
+    ("cin32_cout_72_pad", 32, 0, 72, (1, 2, 3, 9)),
+    ("cin512_deep_k", 512, 0, 128, (1, 2, 4, 16)),
+]
+
+
+@pytest.mark.parametrize("tile", ["16", "32"])
+@pytest.mark.parametrize("name,c1,c2,cout,dims", HALO3_CASES, ids=[c[0] for c in HALO3_CASES])
+def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
+    """The LDS halo-tile 3x3x3 kernel (conv3_halo.hip) on aligned, ragged, multi-tile and two-source inputs;
+    the gather-GEMM kernel on the same problem must agree with it to bf16 output rounding."""
+    n, d, h, w = dims
+    x1 = bf16_round(formula_input((n, c1, d, h, w), 1))
+    x2 = bf16_round(formula_input((n, c2, d, h, w), 2)) if c2 else None
+    x = torch.cat([x1, x2], 1) if c2 else x1
+    wt = bf16_round(_w((cout, c1 + c2, 3, 3, 3), 3))
+    b = formula_input((cout,), 4) * 0.1
+    ref = F.conv3d(x, wt, b, padding=1)
+    groups = 8
+    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
+    monkeypatch.setenv("CTSI_CONV_HALO_TILE", tile)     # 4x4x16 (16x16x32 MFMA) or 4x2x32 (32x32x16 MFMA) tile
+    y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=groups)
+    assert rel_l2(y, ref) < CONV_TOL, name
+    rg = ref.reshape(n, groups, -1).double()
+    assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+    assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
+    monkeypatch.delenv("CTSI_CONV_FORCE_HALO3")
+    monkeypatch.setenv("CTSI_CONV_NO_HALO3", "1")
+    y2, _ = G.run_conv(x1, x2, wt, b)
+    assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
 def test_conv_fp32_strided_output_tanh_and_padded_input(G):
     # VAE decoder head: 128 -> 1 channel, tanh, written straight to fp32 NCDHW (models/vae.py:202-203)
     x = bf16_round(formula_input((1, 128, 3, 6, 5), 5))

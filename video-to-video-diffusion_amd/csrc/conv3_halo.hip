@@ -1,0 +1,693 @@
+// 3x3x3 stride-1 convolution with an LDS-staged D x H x W input halo tile (gfx950 / MI355X).
+//
+// The gather-GEMM kernel (conv_mfma.hip) re-stages the activation slab for each of the 27 taps and runs
+// at a constant L2->LDS fill rate (~8-10 TB/s): bytes per flop bound it.  This kernel stages, per
+// 32-channel chunk, the (TD+2) x (TH+2) x (TW+2) = 6 x 6 x 18 halo tile of the input ONCE (buffer_load ... lds,
+// out-of-volume voxels are out-of-range buffer offsets -> hardware zero fill = the conv's zero padding) and
+// lets all 27 taps read their A operand from it at shifted LDS addresses; only the weights stream per tap.
+// Fill traffic per 256x128 output tile and 32-channel chunk: 41 KB halo + 27 x 8 KB weights for 56.6 MFLOP
+// (220 flop/B, vs 85 flop/B for the 256x128 gather tile).
+//
+// MFMA: v_mfma_f32_16x16x32_bf16.  An A operand tile is one W-line of 16 output voxels x 32 channels, so a
+// 32-lane half of a ds_read_b64 always touches 16 CONSECUTIVE 64-byte halo rows whatever the tap shift is;
+// with the 16-byte chunk swizzle  slot = chunk ^ ((row >> 2) & 3)  and the two 8-byte halves read in
+// opposite order by odd/even k-groups, every fragment read is bank-conflict free.  The weight tile uses the
+// same 64-byte-row layout (pre-swizzled at pack time, so its DMA is a linear copy) and the same read code;
+// the half swap permutes k identically in both operands, which leaves the dot product unchanged.
+//
+// Block = 8 waves (4 along M x 2 along N), output tile 4 x 4 x 16 voxels x 128 couts, 64 fp32 accumulators
+// per lane.  Per step = one (kd, kh) pair = 3 taps: 3 weight DMAs + <=1 halo DMA per wave, 48 ds_read_b64,
+// 48 MFMA, one barrier.  Halo tiles are double buffered across chunks, weight slots across steps.
+#include "ctsi_internal.h"
+#include <string.h>
+
+typedef __attribute__((address_space(3))) void* lptr3_t;
+
+namespace h3 {
+constexpr int TD = 4, TH = 4, TW = 16;
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+constexpr int HV = HD * HH * HW;               // 648 halo voxels
+constexpr int HALO_INSTR = (HV + 15) / 16;     // 41 DMA wave-instructions of 16 voxels x 64 B
+constexpr int HALO_BYTES = HALO_INSTR * 1024;  // 41984
+constexpr int BM = TD * TH * TW;               // 256
+constexpr int BN = 128;
+constexpr int WSLOT_BYTES = 3 * BN * 64;       // 3 taps x 128 couts x 32 ch bf16
+constexpr int NW = 8, NTH = 512;
+constexpr int OFF_W = 2 * HALO_BYTES;
+constexpr int OFF_ROW = OFF_W + 2 * WSLOT_BYTES;
+constexpr int OFF_CS = OFF_ROW + BM * 8;
+constexpr int LDS_BYTES = OFF_CS + 4 * BN * 8;  // column-sum scratch [4][BN][2] floats
+}  // namespace h3
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// buffer resource words for a raw (stride 0) byte buffer; every input is wave-uniform
+__device__ __forceinline__ v4i_t h3_make_rsrc(const void* ptr, unsigned num_bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    v4i_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull));
+    r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffull));
+    r.z = (int)num_bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
+// One LDS-DMA wave instruction (64 lanes x 16 B -> 1 KiB at `lds_addr`), issued from inline asm so that
+// hipcc does not order later ds_reads behind it with a vmcnt(0): completion is waited for by hand
+// (s_waitcnt vmcnt(0) + s_barrier before the data is read, see the main loop).
+__device__ __forceinline__ void h3_dma16(const v4i_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+        : "memory");
+}
+
+__device__ __forceinline__ int xcd_remap_h(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + (orig >> 3);
+}
+
+__global__ void __launch_bounds__(512)
+conv3_halo_kernel(const Conv3HaloParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace h3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long* s_rowoff = reinterpret_cast<long long*>(smem + OFF_ROW);
+    float* s_cs = reinterpret_cast<float*>(smem + OFF_CS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- block decode: n-tiles of one m-tile adjacent, XCD-contiguous m ranges --------------------------
+    const int bid = xcd_remap_h(blockIdx.x, gridDim.x);
+    const int mt = bid / p.ntiles_n;
+    const int nt = bid - mt * p.ntiles_n;
+    const int n0 = nt * BN;
+    const int nb = mt / p.tps;
+    int r0 = mt - nb * p.tps;
+    const int tD = r0 / (p.tilesH * p.tilesW);
+    r0 -= tD * p.tilesH * p.tilesW;
+    const int tH = r0 / p.tilesW;
+    const int tW = r0 - tH * p.tilesW;
+    const int d0 = tD * TD, h0 = tH * TH, w0 = tW * TW;
+
+    // output row offsets (row = line*16 + m, line = ld*TH + lh)
+    if (tid < BM) {
+        const int m = tid & 15, line = tid >> 4;
+        const int d = d0 + line / TH, h = h0 + line % TH, w = w0 + m;
+        long long off = -1;
+        if (d < p.Do && h < p.Ho && w < p.Wo)
+            off = ((((long long)nb * p.Do + d) * p.Ho + h) * p.Wo + w) * p.cout_stride + p.c_off;
+        s_rowoff[tid] = off;
+    }
+
+    // ---- halo DMA descriptors ------------------------------------------------------------------------------
+    // base = first input plane this tile can touch; per-lane voxel offsets are relative to it
+    int dlo = d0 + p.dshift - 1;
+    dlo = dlo < 0 ? 0 : dlo;
+    const long long basevox = ((long long)(nb * p.Di + dlo) * p.Hi) * p.Wi;
+    const char* b1 = reinterpret_cast<const char*>(p.x1) + basevox * p.C1 * 2;
+    const char* b2 = reinterpret_cast<const char*>(p.x2) + basevox * p.C2 * 2;
+    const v4i_t rs1 = h3_make_rsrc(b1, 0x7fffffffu);
+    const v4i_t rs2 = h3_make_rsrc(b2, 0x7fffffffu);
+    const char* wb = reinterpret_cast<const char*>(p.w) + (long long)n0 * 64;
+    const v4i_t rsw = h3_make_rsrc(wb, 0x7fffffffu);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;   // LDS byte address of the dynamic region
+
+    // this wave issues halo instructions j = wave + 8*i (i < 6, j < 41); lane -> voxel 16j + (lane>>2)
+    const int hq = (lane & 3) ^ (lane >> 4);  // logical 8-channel chunk landing in this lane's 16-B slot
+    int hrel[6];                               // voxel index relative to basevox, or -1
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int j = wave + 8 * i;
+        const int v = j * 16 + (lane >> 2);
+        const int hd = v / (HH * HW), rem = v - hd * (HH * HW);
+        const int hh = rem / HW, hw = rem - hh * HW;
+        const int gd = d0 + p.dshift - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+        const bool ok = (j < HALO_INSTR) && (v < HV) && gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 &&
+                        gw < p.Wi;
+        hrel[i] = ok ? ((gd - dlo) * p.Hi + gh) * p.Wi + gw : -1;
+    }
+    const unsigned w_voff = (unsigned)wave * 1024u + (unsigned)lane * 16u;
+    const int C1 = p.C1, C2 = p.C2, CoutPad = p.CoutPad, nchunks = p.nchunks;
+
+    // `hoff`/`woff`: byte offset of the destination buffer inside the dynamic LDS region
+    auto issue_halo = [&](int cc, int i, int hoff) {  // one DMA instruction (16 voxels) of chunk cc
+        const int j = wave + 8 * i;
+        if (j >= HALO_INSTR) return;
+        const int ch0 = cc * 32;
+        const bool second = ch0 >= C1;
+        const unsigned cbytes = (unsigned)((second ? C2 : C1) * 2);
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? ch0 - C1 : ch0) * 2);
+        int hsel = hrel[0];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) hsel = (i == q) ? hrel[q] : hsel;
+        const unsigned voff = hsel >= 0 ? (unsigned)hsel * cbytes + (unsigned)hq * 16u : 0x80000000u;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + hoff + j * 1024));
+        if (second)
+            h3_dma16(rs2, dst, voff, soff);
+        else
+            h3_dma16(rs1, dst, voff, soff);
+    };
+    auto issue_weights = [&](int s, int woff) {  // the 3 taps of step s: wave loads rows 16w..16w+15 of each
+        const int cc = s / 9, g = s - cc * 9;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((cc * 27 + g * 3 + i) * CoutPad) * 64);
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + woff + i * (BN * 64) + wave * 1024));
+            h3_dma16(rsw, dst, w_voff, soff);
+        }
+    };
+
+    // ---- fragment addressing -----------------------------------------------------------------------------------
+    const int kg = lane >> 4, m = lane & 15;
+    const int half0 = (kg & 1) * 8;
+    const int va = (wm * HH) * HW + m;                    // halo voxel of (ld = wm, lh = 0, kw = 0) before taps
+    const int rowb = wn * 64 + m;                          // weight row of n-tile 0 of this wave
+    const int b_off = rowb * 64 + ((kg ^ ((rowb >> 2) & 3)) << 4) + half0;   // + j*1024 + kw*BN*64
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- software-pipelined main loop ---------------------------------------------------------------------------------
+    // Block (s, kw) always uses fragment set F[kw]; per step:
+    //   LOAD F1(s,1) | MFMA F0 | LOAD F2(s,2) | MFMA F1 | lgkmcnt(0), vmcnt(0), barrier | DMA W(s+2), halo piece |
+    //   LOAD F0(s+1,0) | MFMA F2
+    // so every LDS read has 16 MFMAs (256 cycles) of cover and the barrier sits between two MFMA clusters.
+    // DMA W(s+2) reuses weight slot s&1: every wave has finished reading it (its F2 load was waited for
+    // before the barrier).  Halo pieces of chunk cc+1 go to the other halo buffer during steps g < 6 of chunk cc.
+    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4], fa2[4], fb2[4];
+    const int S = nchunks * 9;
+    // per-n-tile weight row offsets, made opaque so that hipcc cannot fuse two fragments' reads into
+    // ds_read2st64_b64 (half the LDS rate and 32-bank addressing: it reintroduces bank conflicts)
+    int boffj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        boffj[j] = j * 1024;
+        asm volatile("" : "+v"(boffj[j]));
+    }
+
+#define H3_LOAD(FA, FB, HBUF, WBUF, VS, KW)                                                                    \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
+            const int v_ = (VS) + i_ * HW + (KW);                                                              \
+            const char* a_ = (HBUF) + v_ * 64 + ((kg ^ ((v_ >> 2) & 3)) << 4);                                 \
+            const uint2 lo_ = *reinterpret_cast<const uint2*>(a_ + half0);                                     \
+            const uint2 hi_ = *reinterpret_cast<const uint2*>(a_ + (half0 ^ 8));                               \
+            const uint4 u_ = make_uint4(lo_.x, lo_.y, hi_.x, hi_.y);                                           \
+            FA[i_] = *reinterpret_cast<const bf16x8*>(&u_);                                                    \
+        }                                                                                                      \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                     \
+            const char* b_ = (WBUF) + (KW) * (BN * 64) + boffj[j_];                                            \
+            const uint2 lo_ = *reinterpret_cast<const uint2*>(b_);                                             \
+            const uint2 hi_ = *reinterpret_cast<const uint2*>(b_ + ((half0 ^ 8) - half0));                     \
+            const uint4 u_ = make_uint4(lo_.x, lo_.y, hi_.x, hi_.y);                                           \
+            FB[j_] = *reinterpret_cast<const bf16x8*>(&u_);                                                    \
+        }                                                                                                      \
+    }
+#define H3_MFMA(FA, FB)                                                                                        \
+    {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)       \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[i_], FB[j_], acc[i_][j_], 0, 0, 0);       \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+    }
+
+    // prologue: halo of chunk 0, weights of steps 0 and 1
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_halo(0, i, 0);
+    issue_weights(0, OFF_W);
+    if (S > 1) issue_weights(1, OFF_W + WSLOT_BYTES);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    H3_LOAD(fa0, fb0, smem, smem + OFF_W + b_off, va, 0);
+
+    int cc = 0, g = 0;
+    for (int s = 0; s < S; ++s) {
+        const char* hbuf = smem + (cc & 1) * HALO_BYTES;
+        const char* wbuf = smem + OFF_W + (s & 1) * WSLOT_BYTES + b_off;
+        const int kd = g / 3, kh = g - kd * 3;
+        const int vs = va + (kd * HH + kh) * HW;
+        H3_LOAD(fa1, fb1, hbuf, wbuf, vs, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        H3_MFMA(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        H3_LOAD(fa2, fb2, hbuf, wbuf, vs, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        H3_MFMA(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        // next step's operands: every wave's reads of this step's weight slot are complete, all DMA landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < S) issue_weights(s + 2, OFF_W + (s & 1) * WSLOT_BYTES);
+        if (g < 6 && cc + 1 < nchunks) issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
+        int g2 = g + 1, cc2 = cc;
+        if (g2 == 9) {
+            g2 = 0;
+            ++cc2;
+        }
+        if (s + 1 < S) {
+            const int kd2 = g2 / 3, kh2 = g2 - kd2 * 3;
+            H3_LOAD(fa0, fb0, smem + (cc2 & 1) * HALO_BYTES, smem + OFF_W + ((s + 1) & 1) * WSLOT_BYTES + b_off,
+                    va + (kd2 * HH + kh2) * HW, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        H3_MFMA(fa2, fb2);
+        __builtin_amdgcn_sched_barrier(0);
+        g = g2;
+        cc = cc2;
+    }
+#undef H3_LOAD
+#undef H3_MFMA
+    __syncthreads();
+
+    // ---- epilogue: + bias, column sums, bf16 tile through LDS, full-row stores ------------------------------------------
+    bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16 = 64 KB (the two halo buffers)
+    const bool want_sums = p.colsum != nullptr;
+    unsigned vbits = 0;  // validity of this lane's 16 rows: bit (i*4 + r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (wm * 4 + i) * 16 + kg * 4 + r;
+            vbits |= (unsigned)(s_rowoff[row] >= 0) << (i * 4 + r);
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = wn * 64 + j * 16 + m;
+        const int co = n0 + col;
+        const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (wm * 4 + i) * 16 + kg * 4 + r;
+                const float v = acc[i][j][r] + bv;
+                s_tile[row * BN + col] = f32_to_bf16(v);
+                if (want_sums) {
+                    const float vm = ((vbits >> (i * 4 + r)) & 1u) ? v : 0.0f;
+                    s1 += vm;
+                    s2 += vm * vm;
+                }
+            }
+        if (want_sums) {
+            s1 += __shfl_xor(s1, 16);
+            s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (kg == 0) {
+                s_cs[(wm * BN + col) * 2 + 0] = s1;
+                s_cs[(wm * BN + col) * 2 + 1] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    if (want_sums && tid < BN) {
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t1 += s_cs[(q * BN + tid) * 2 + 0];
+            t2 += s_cs[(q * BN + tid) * 2 + 1];
+        }
+        const long long slab = (long long)p.mtiles * CoutPad;
+        p.colsum[(long long)mt * CoutPad + n0 + tid] = t1;
+        p.colsum[slab + (long long)mt * CoutPad + n0 + tid] = t2;
+    }
+    {
+        constexpr int CPR = BN / 8;
+        bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+        for (int c = tid; c < BM * CPR; c += NTH) {
+            const int row = c / CPR, ch = c - row * CPR;
+            const long long off = s_rowoff[row];
+            const int co = n0 + ch * 8;
+            if (off >= 0 && co < p.Cout) {
+                const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
+                *reinterpret_cast<uint4*>(y + off + co) = v;
+            }
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// =====================================================================================================
+// 32-wide variant: output tile 4 x 2 x 32 voxels, v_mfma_f32_32x32x16_bf16.  An A operand tile is a W-line
+// of 32 consecutive halo rows, read with ds_read_b128 (each 16-lane group of a b128 read then covers 16
+// distinct (row & 3, chunk ^ swizzle) bank slots for every tap shift).  Half the MFMA and LDS-read
+// instruction count of the 16-wide kernel for the same FLOPs (the 16x16x32 form holds the SIMD's issue
+// port for 8 of its 16 cycles, the 32x32x16 form for 8 of 32), used whenever W >= 32-ish.
+// =====================================================================================================
+namespace h32 {
+constexpr int TD = 4, TH = 2, TW = 32;
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+constexpr int HV = HD * HH * HW;               // 816 halo voxels
+constexpr int HALO_INSTR = (HV + 15) / 16;     // 51
+constexpr int HALO_BYTES = HALO_INSTR * 1024;  // 52224
+constexpr int BM = TD * TH * TW;               // 256
+constexpr int BN = 128;
+constexpr int WSLOT_BYTES = 3 * BN * 64;
+constexpr int NTH = 512;
+constexpr int OFF_W = 2 * HALO_BYTES;
+constexpr int OFF_ROW = OFF_W + 2 * WSLOT_BYTES;
+constexpr int OFF_CS = OFF_ROW + BM * 8;
+constexpr int LDS_BYTES = OFF_CS + 4 * BN * 8;  // 159744 <= 163840
+constexpr int NPIECE = (HALO_INSTR + 7) / 8;   // 7 halo DMA instructions per wave and chunk
+}  // namespace h32
+
+__global__ void __launch_bounds__(512)
+conv3_halo32_kernel(const Conv3HaloParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace h32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long* s_rowoff = reinterpret_cast<long long*>(smem + OFF_ROW);
+    float* s_cs = reinterpret_cast<float*>(smem + OFF_CS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int bid = xcd_remap_h(blockIdx.x, gridDim.x);
+    const int mt = bid / p.ntiles_n;
+    const int nt = bid - mt * p.ntiles_n;
+    const int n0 = nt * BN;
+    const int nb = mt / p.tps;
+    int r0 = mt - nb * p.tps;
+    const int tD = r0 / (p.tilesH * p.tilesW);
+    r0 -= tD * p.tilesH * p.tilesW;
+    const int tH = r0 / p.tilesW;
+    const int tW = r0 - tH * p.tilesW;
+    const int d0 = tD * TD, h0 = tH * TH, w0 = tW * TW;
+
+    if (tid < BM) {   // row = line*32 + m, line = ld*TH + lh
+        const int mm = tid & 31, line = tid >> 5;
+        const int d = d0 + line / TH, h = h0 + line % TH, w = w0 + mm;
+        long long off = -1;
+        if (d < p.Do && h < p.Ho && w < p.Wo)
+            off = ((((long long)nb * p.Do + d) * p.Ho + h) * p.Wo + w) * p.cout_stride + p.c_off;
+        s_rowoff[tid] = off;
+    }
+
+    int dlo = d0 + p.dshift - 1;
+    dlo = dlo < 0 ? 0 : dlo;
+    const long long basevox = ((long long)(nb * p.Di + dlo) * p.Hi) * p.Wi;
+    const v4i_t rs1 = h3_make_rsrc(reinterpret_cast<const char*>(p.x1) + basevox * p.C1 * 2, 0x7fffffffu);
+    const v4i_t rs2 = h3_make_rsrc(reinterpret_cast<const char*>(p.x2) + basevox * p.C2 * 2, 0x7fffffffu);
+    const v4i_t rsw = h3_make_rsrc(reinterpret_cast<const char*>(p.w) + (long long)n0 * 64, 0x7fffffffu);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;
+
+    const int hq = (lane & 3) ^ (lane >> 4);
+    int hrel[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int j = wave + 8 * i;
+        const int v = j * 16 + (lane >> 2);
+        const int hd = v / (HH * HW), rem = v - hd * (HH * HW);
+        const int hh = rem / HW, hw = rem - hh * HW;
+        const int gd = d0 + p.dshift - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+        const bool ok = (j < HALO_INSTR) && (v < HV) && gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 &&
+                        gw < p.Wi;
+        hrel[i] = ok ? ((gd - dlo) * p.Hi + gh) * p.Wi + gw : -1;
+    }
+    const unsigned w_voff = (unsigned)wave * 1024u + (unsigned)lane * 16u;
+    const int C1 = p.C1, C2 = p.C2, CoutPad = p.CoutPad, nchunks = p.nchunks;
+
+    auto issue_halo = [&](int cc, int i, int hoff) {
+        const int j = wave + 8 * i;
+        if (j >= HALO_INSTR) return;
+        const int ch0 = cc * 32;
+        const bool second = ch0 >= C1;
+        const unsigned cbytes = (unsigned)((second ? C2 : C1) * 2);
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? ch0 - C1 : ch0) * 2);
+        int hsel = hrel[0];
+#pragma unroll
+        for (int q = 1; q < NPIECE; ++q) hsel = (i == q) ? hrel[q] : hsel;
+        const unsigned voff = hsel >= 0 ? (unsigned)hsel * cbytes + (unsigned)hq * 16u : 0x80000000u;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + hoff + j * 1024));
+        if (second)
+            h3_dma16(rs2, dst, voff, soff);
+        else
+            h3_dma16(rs1, dst, voff, soff);
+    };
+    auto issue_weights = [&](int s, int woff) {
+        const int cc = s / 9, g = s - cc * 9;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((cc * 27 + g * 3 + i) * CoutPad) * 64);
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + woff + i * (BN * 64) + wave * 1024));
+            h3_dma16(rsw, dst, w_voff, soff);
+        }
+    };
+
+    // fragment addressing: lane -> row r = lane & 31 of the 32-row operand tile, k-group hk = lane >> 5
+    const int hk = lane >> 5, r = lane & 31;
+    const int va = (wm * HH) * HW + r;                       // halo voxel of (ld = wm, lh = 0) before taps
+    const int rowb = wn * 64 + r;
+    const int b_off = rowb * 64 + ((hk ^ ((rowb >> 2) & 3)) << 4);   // k-step 0; k-step 1 = ^32; n-tile 1 = +2048
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+
+    bf16x8 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2], fa2[2][2], fb2[2][2];   // [tile][k-step]
+    const int S = nchunks * 9;
+    int boffj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        boffj[j] = j * 2048;
+        asm volatile("" : "+v"(boffj[j]));
+    }
+
+#define H32_LOAD(FA, FB, HBUF, WBUF, VS, KW)                                                                   \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
+            const int v_ = (VS) + i_ * HW + (KW);                                                              \
+            const int o_ = v_ * 64 + ((hk ^ ((v_ >> 2) & 3)) << 4);                                            \
+            FA[i_][0] = *reinterpret_cast<const bf16x8*>((HBUF) + o_);                                         \
+            FA[i_][1] = *reinterpret_cast<const bf16x8*>((HBUF) + (o_ ^ 32));                                  \
+        }                                                                                                      \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                     \
+            const int o_ = b_off + (KW) * (BN * 64) + boffj[j_];                                               \
+            FB[j_][0] = *reinterpret_cast<const bf16x8*>((WBUF) + o_);                                         \
+            FB[j_][1] = *reinterpret_cast<const bf16x8*>((WBUF) + (o_ ^ 32));                                  \
+        }                                                                                                      \
+    }
+#define H32_MFMA(FA, FB)                                                                                       \
+    {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)       \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) acc[i_][j_] =                                     \
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i_][k_], FB[j_][k_], acc[i_][j_], 0, 0, 0);         \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+    }
+
+    // Software pipeline (blocks b0,b1,b2 = the three kw taps of a step; block b always uses fragment set F[b]):
+    //   phase 0: MFMA b0(s)  interleaved with LOAD b2(s)      -> F2
+    //   lgkmcnt(0), vmcnt, barrier; DMA W(s+2) into the slot just drained, one halo piece of the next chunk
+    //   phase 1: MFMA b1(s)  interleaved with LOAD b0(s+1)    -> F0
+    //   phase 2: MFMA b2(s)  interleaved with LOAD b1(s+1)    -> F1
+    // Every fragment set is loaded two phases before it is used; inside a phase the 8 ds_read_b128 are
+    // placed one per MFMA gap (sched_group_barrier), so neither wave of a SIMD has a load-only phase.
+#define H32_PHASE(FAc, FBc, FAl, FBl, HBUF, WBUF, VS, KW, DOLOAD)                                              \
+    {                                                                                                          \
+        H32_LOAD(FAl, FBl, HBUF, WBUF, VS, KW);                                                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)       \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) acc[i_][j_] =                                     \
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(FAc[i_][k_], FBc[j_][k_], acc[i_][j_], 0, 0, 0);       \
+        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) issue_halo(0, i, 0);
+    issue_weights(0, OFF_W);
+    if (S > 1) issue_weights(1, OFF_W + WSLOT_BYTES);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    H32_LOAD(fa0, fb0, smem, smem + OFF_W, va, 0);
+    H32_LOAD(fa1, fb1, smem, smem + OFF_W, va, 1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    int cc = 0, g = 0;
+    bool halo_in_flight = false;   // wave-uniform
+    for (int s = 0; s < S; ++s) {
+        const char* hbuf = smem + (cc & 1) * HALO_BYTES;
+        const char* wbuf = smem + OFF_W + (s & 1) * WSLOT_BYTES;
+        const int kd = g / 3, kh = g - kd * 3;
+        const int vs = va + (kd * HH + kh) * HW;
+        H32_PHASE(fa0, fb0, fa2, fb2, hbuf, wbuf, vs, 2, true);
+        // every wave has drained this step's weight slot; the weight DMA of the previous step has landed.
+        // A halo piece issued in the previous step (the youngest VMEM op of this wave) may stay in flight
+        // one more step: it streams from HBM and is only consumed after the chunk switch.
+        if (halo_in_flight)
+            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < S && !(p.dbg & 2)) issue_weights(s + 2, OFF_W + (s & 1) * WSLOT_BYTES);
+        halo_in_flight = (g < NPIECE - 1) && (cc + 1 < nchunks) && !(p.dbg & 1) && (wave + 8 * g < HALO_INSTR);
+        if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1)) issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
+        int g2 = g + 1, cc2 = cc;
+        if (g2 == 9) {
+            g2 = 0;
+            ++cc2;
+        }
+        // (the last step's look-ahead loads read stale but in-bounds LDS and are never consumed)
+        const char* hbuf2 = smem + (cc2 & 1) * HALO_BYTES;
+        const char* wbuf2 = smem + OFF_W + ((s + 1) & 1) * WSLOT_BYTES;
+        const int kd2 = g2 / 3, kh2 = g2 - kd2 * 3;
+        const int vs2 = va + (kd2 * HH + kh2) * HW;
+        __builtin_amdgcn_sched_barrier(0);
+        H32_PHASE(fa1, fb1, fa0, fb0, hbuf2, wbuf2, vs2, 0, true);
+        H32_PHASE(fa2, fb2, fa1, fb1, hbuf2, wbuf2, vs2, 1, true);
+        g = g2;
+        cc = cc2;
+    }
+#undef H32_PHASE
+#undef H32_LOAD
+#undef H32_MFMA
+    __syncthreads();
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16 = 64 KB
+    const bool want_sums = p.colsum != nullptr;
+    const int lhi = lane >> 5, lcol = lane & 31;
+    unsigned vbits[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        unsigned vb = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhi;
+            vb |= (unsigned)(s_rowoff[row] >= 0) << q;
+        }
+        vbits[i] = vb;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + lcol;
+        const int co = n0 + col;
+        const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16_t* trow = s_tile + ((wm * 2 + i) * 32 + 4 * lhi) * BN + col;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float v = acc[i][j][q] + bv;
+                trow[((q & 3) + 8 * (q >> 2)) * BN] = f32_to_bf16(v);
+                if (want_sums) {
+                    const float vm = ((vbits[i] >> q) & 1u) ? v : 0.0f;
+                    s1 += vm;
+                    s2 += vm * vm;
+                }
+            }
+        }
+        if (want_sums) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lhi == 0) {
+                s_cs[(wm * BN + col) * 2 + 0] = s1;
+                s_cs[(wm * BN + col) * 2 + 1] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    if (want_sums && tid < BN) {
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t1 += s_cs[(q * BN + tid) * 2 + 0];
+            t2 += s_cs[(q * BN + tid) * 2 + 1];
+        }
+        const long long slab = (long long)p.mtiles * CoutPad;
+        p.colsum[(long long)mt * CoutPad + n0 + tid] = t1;
+        p.colsum[slab + (long long)mt * CoutPad + n0 + tid] = t2;
+    }
+    {
+        constexpr int CPR = BN / 8;
+        bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+        for (int c = tid; c < BM * CPR; c += NTH) {
+            const int row = c / CPR, ch = c - row * CPR;
+            const long long off = s_rowoff[row];
+            const int co = n0 + ch * 8;
+            if (off >= 0 && co < p.Cout) {
+                const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
+                *reinterpret_cast<uint4*>(y + off + co) = v;
+            }
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---- weight packing: fp32 (cout, cin, 3,3,3) -> bf16 [chunk][tap][cout_pad][32], 16-B chunks swizzled per row --------
+__global__ void conv3_halo_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int CoutPad,
+                                       int Cin, int CinW, int nchunks) {
+    const long long total = (long long)nchunks * 27 * CoutPad * 32;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 31);                 // physical element within the 64-B row
+        const long long row = idx >> 5;                // (chunk*27 + tap)*CoutPad + cout
+        const int co = (int)(row % CoutPad);
+        const long long ct = row / CoutPad;
+        const int tap = (int)(ct % 27), cc = (int)(ct / 27);
+        const int slot = e >> 3;
+        const int q = slot ^ ((co >> 2) & 3);          // logical chunk stored in this physical slot
+        const int ci = cc * 32 + q * 8 + (e & 7);
+        float v = 0.0f;
+        if (co < Cout && ci < CinW) v = w[((long long)co * CinW + ci) * 27 + tap];
+        out[idx] = f32_to_bf16(v);
+    }
+}
+
+extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
+                                    void* stream) {
+    CTSI_CHECK_ARG(w && packed && cin % 32 == 0, "ctsi_conv3_halo_pack: bad arguments");
+    const int nchunks = cin / 32;
+    const long long total = (long long)nchunks * 27 * cout_pad * 32;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(conv3_halo_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed,
+                       cout, cout_pad, cin, cin_w, nchunks);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void* stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)h3::LDS_BYTES);
+        hipFuncSetAttribute((const void*)conv3_halo32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)h32::LDS_BYTES);
+        attr_done = true;
+    }
+    const int grid = hp->mtiles * hp->ntiles_n;
+    if (wide)
+        hipLaunchKernelGGL(conv3_halo32_kernel, dim3(grid), dim3(512), h32::LDS_BYTES, (hipStream_t)stream, *hp);
+    else
+        hipLaunchKernelGGL(conv3_halo_kernel, dim3(grid), dim3(512), h3::LDS_BYTES, (hipStream_t)stream, *hp);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}

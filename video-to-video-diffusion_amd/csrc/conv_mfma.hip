@@ -479,6 +479,7 @@ struct ctsi_conv_plan {
     int8_t pH[4], pW[4];
     int tap_margin[4], ad_min[4];
     int fast, dshift;
+    int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip)
     double flops;
 };
 
@@ -654,9 +655,34 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             }
         }
     }
+    {   // 3x3x3 / stride 1 / pad 1 with whole 32-channel chunks per source: LDS halo-tile kernel, provided its
+        // fixed 4x4x16 tile does not waste more than ~30 % of the rows and the per-tile halo fits 2^31 bytes
+        const bool k3 = !d.transposed && d.kd == 3 && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 &&
+                        d.pd == 1 && d.ph == 1 && d.pw == 1;
+        const long long rows = (long long)p->Dr * p->Hr * p->Wr;
+        const long long padded = (long long)ceil_div(p->Dr, 4) * ceil_div(p->Hr, 4) * ceil_div(p->Wr, 16) * 256;
+        const long long padded32 = (long long)ceil_div(p->Dr, 4) * ceil_div(p->Hr, 2) * ceil_div(p->Wr, 32) * 256;
+        const int cmax = d.c1 > d.c2 ? d.c1 : d.c2;
+        const double extent = 8.0 * d.hi * d.wi * cmax * 2.0;
+        p->halo3 = k3 && !p->small && d.c1 % 32 == 0 && d.c2 % 32 == 0 && d.cout >= 64 && d.cout % 8 == 0 &&
+                   p->CinW == p->Cin && (rows * 10 >= padded * 7 || getenv("CTSI_CONV_FORCE_HALO3")) && extent < 2.0e9 &&
+                   !getenv("CTSI_CONV_NO_HALO3");
+        if (p->halo3) {
+            p->BM = 256;
+            p->BN = 128;
+            const char* hv = getenv("CTSI_CONV_HALO_TILE");   // "16" | "32" (tuning aid)
+            if ((padded32 <= padded && !(hv && !strcmp(hv, "16"))) || (hv && !strcmp(hv, "32"))) p->halo3 = 2;
+        }
+    }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
-    choose_tile(p->BM, p->Dr, p->Hr, p->Wr, &p->TD, &p->TH, &p->TW);
+    if (p->halo3 == 2) {
+        p->TD = 4; p->TH = 2; p->TW = 32;
+    } else if (p->halo3) {
+        p->TD = 4; p->TH = 4; p->TW = 16;
+    } else {
+        choose_tile(p->BM, p->Dr, p->Hr, p->Wr, &p->TD, &p->TH, &p->TW);
+    }
     p->lTH = ilog2(p->TH);
     p->lTW = ilog2(p->TW);
     p->tilesD = ceil_div(p->Dr, p->TD);
@@ -687,7 +713,9 @@ extern "C" int ctsi_conv_plan_out_dims(const ctsi_conv_plan* p, int* d, int* h, 
     return CTSI_OK;
 }
 extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
-    return p ? (size_t)p->nclass * p->CoutPad * p->Ktot * 2 : 0;
+    if (!p) return 0;
+    if (p->halo3) return (size_t)(p->Cin / 32) * 27 * p->CoutPad * 64;
+    return (size_t)p->nclass * p->CoutPad * p->Ktot * 2;
 }
 extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) { return p ? p->nclass * p->mtiles : 0; }
 extern "C" int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* p) { return p ? p->tps : 0; }
@@ -697,7 +725,7 @@ extern "C" int ctsi_conv_plan_config(const ctsi_conv_plan* p, int* bm, int* bn, 
     CTSI_CHECK_ARG(p, "ctsi_conv_plan_config: null plan");
     if (bm) *bm = p->BM;
     if (bn) *bn = p->BN;
-    if (mode) *mode = p->small ? 1 : (p->fast ? 2 : 0);
+    if (mode) *mode = p->halo3 ? 2 + p->halo3 : (p->small ? 1 : (p->fast ? 2 : 0));
     return CTSI_OK;
 }
 
@@ -712,6 +740,7 @@ extern "C" int ctsi_conv_plan_set_weight_cin(ctsi_conv_plan* p, int cin_w) {
 extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float* w, void* packed,
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
+    if (p->halo3) return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
     PackParams q;
     memset(&q, 0, sizeof(q));
     q.w = w;
@@ -778,6 +807,33 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
                        "ctsi_conv_fwd: bf16 output needs cout, cout_stride, c_off multiples of 8 "
                        "(cout=%d stride=%d off=%d)", p->d.cout, o->cout_stride, o->c_off);
     }
+    if (p->halo3 && o->mode == 0 && o->act == 0) {
+        Conv3HaloParams h;
+        memset(&h, 0, sizeof(h));
+        h.x1 = (const bf16_t*)x1;
+        h.x2 = (const bf16_t*)(x2 ? x2 : x1);
+        h.w = (const bf16_t*)packed_w;
+        h.bias = bias;
+        h.y = o->y;
+        h.colsum = o->colsum;
+        h.C1 = p->d.c1; h.C2 = p->d.c2;
+        h.Di = p->d.di; h.Hi = p->d.hi; h.Wi = p->d.wi;
+        h.Do = p->Do; h.Ho = p->Ho; h.Wo = p->Wo;
+        h.dshift = p->dshift;
+        h.tilesD = p->tilesD; h.tilesH = p->tilesH; h.tilesW = p->tilesW; h.tps = p->tps; h.mtiles = p->mtiles;
+        h.ntiles_n = p->ntiles_n;
+        h.nchunks = p->Cin / 32;
+        h.Cout = p->d.cout; h.CoutPad = p->CoutPad;
+        h.cout_stride = o->cout_stride; h.c_off = o->c_off;
+        {
+            static const char* dbgf = getenv("CTSI_DEBUG_FLAGS");
+            h.dbg = dbgf ? atoi(dbgf) : 0;
+            static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
+            if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
+        }
+        return ctsi_conv3_halo_launch(&h, p->halo3 == 2, stream);
+    }
+    CTSI_CHECK_ARG(!p->halo3, "ctsi_conv_fwd: the 3x3x3 halo-tile plan supports bf16 NDHWC output without activation");
     ConvKParams k;
     memset(&k, 0, sizeof(k));
     k.x1 = (const bf16_t*)x1;

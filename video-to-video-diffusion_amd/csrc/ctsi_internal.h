@@ -66,3 +66,27 @@ __device__ __forceinline__ float nan_to_num_f(float v) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- conv3_halo.hip (3x3x3 halo-tile kernel), driven through the conv plan in conv_mfma.hip ------------
+struct Conv3HaloParams {
+    const bf16_t* x1;
+    const bf16_t* x2;
+    const bf16_t* w;      // [chunk][27][cout_pad][32], rows pre-swizzled
+    const float* bias;
+    void* y;
+    float* colsum;
+    int C1, C2;
+    int Di, Hi, Wi;       // input dims (Di includes depth halo slices when dshift = 1)
+    int Do, Ho, Wo;       // output dims (== own input dims)
+    int dshift;
+    int tilesD, tilesH, tilesW, tps, mtiles, ntiles_n;
+    int nchunks;          // (C1 + C2) / 32
+    int Cout, CoutPad;
+    int cout_stride, c_off;
+    int dbg;              // timing-only ablation bits (0 in production): 1 no halo DMA after chunk 0, 2 no weight DMA after step 1
+};
+
+extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
+                                    void* stream);
+extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void* stream);
+

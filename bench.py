@@ -9,9 +9,10 @@ conditioning and every weight resident in HBM when the timed region starts.  The
 reference (264.66 M-param U-Net, latent 8), random-init (seed 0), synthetic input.
 
 Extra objects on the same line:
-  roofline     — the dominant kernel (gather-GEMM MFMA conv, 128x128 tile): algorithmic conv FLOPs of
-                 one U-Net evaluation that this kernel executes / its summed launch time, measured
-                 with HIP events on the engine stream around every launch (eager pass, not the graph).
+  roofline     — the dominant kernel (the one with the most time per step; currently the 3x3x3 LDS
+                 halo-tile conv): algorithmic FLOPs of its launches in one U-Net evaluation / their
+                 summed duration, measured with HIP events on the engine stream around every launch
+                 (eager pass, not the graph).  `conv_family` aggregates every MFMA conv launch.
   cpu_baseline — the CPU oracle (fp32 torch ops, all host cores) timed on a bounded sample:
                  one U-Net evaluation on the config-1 latent (1,8,48,48,48); rank 0, N == 1 only.
   volume_wall_s — wall-clock of the whole 8->48 @512^2 generate() (encode + 51 steps + decode).
@@ -194,15 +195,25 @@ def main():
             step_ms = sum(ms for *_, ms in prof)
             conv_ms = sum(v[2] for v in variants.values())
             conv_fl = sum(v[1] for v in variants.values())
-            # the dominant kernel = the conv_gather_mfma_kernel family (one template, several tile
-            # instantiations); `achieved` covers every launch of the family, per-variant rates are listed
-            roof = {"bound": "mfma", "kernel": "conv_gather_mfma_kernel<WM,WN,TM,TN,MODE> (gather-GEMM conv, all tile variants)",
-                    "achieved": conv_fl / (conv_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
-                    "launches_per_step": sum(v[0] for v in variants.values()),
-                    "avg_launch_ms": conv_ms / max(sum(v[0] for v in variants.values()), 1),
-                    "flops_per_step_this_kernel": conv_fl,
-                    "share_of_step_time": conv_ms / step_ms,
+            dom_key, dom = max(variants.items(), key=lambda kv: kv[1][2])   # dominant kernel = most time per step
+            kernel_names = {"m4": "conv3_halo32_kernel (3x3x3 LDS halo tile 4x2x32, mfma_32x32x16_bf16)",
+                            "m3": "conv3_halo_kernel (3x3x3 LDS halo tile 4x4x16, mfma_16x16x32_bf16)"}
+            dom_name = kernel_names.get(dom_key.rsplit("_", 1)[-1], "conv_gather_mfma_kernel " + dom_key)
+            traffic = None
+            try:  # HBM bytes per launch from the last rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                traffic = pmc[dom_name.split(" ")[0]]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+            ach = dom[1] / (dom[2] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom_name, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                    "launches_per_step": dom[0], "avg_launch_ms": dom[2] / dom[0],
+                    "flops_per_launch_avg": dom[1] / dom[0], "share_of_step_time": dom[2] / step_ms,
+                    "conv_family": {"tflops": conv_fl / (conv_ms * 1e-3) / 1e12,
+                                    "frac": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                                    "launches_per_step": sum(v[0] for v in variants.values()),
+                                    "flops_per_step": conv_fl, "share_of_step_time": conv_ms / step_ms},
                     "other_ops_ms": step_ms - conv_ms,
                     "variants": {k: {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]}
                                  for k, v in sorted(variants.items(), key=lambda kv: -kv[1][2])}}

@@ -55,7 +55,10 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware exp2 / rcp (1 ulp each; results are rounded to bf16 afterwards)
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 __device__ __forceinline__ float nan_to_num_f(float v) {
     // torch.nan_to_num(v, nan=0.0, posinf=1.0, neginf=-1.0)

@@ -177,18 +177,27 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const doub
     const bf16_t* xb = x + (long long)nb * vox * c;
     bf16_t* yb = y + (long long)nb * vox * c;
     const bf16_t* rb = residual ? residual + (long long)nb * vox * c : nullptr;
-    for (long long e = (long long)blockIdx.x * 256 + tid; e < total; e += (long long)gridDim.x * 256) {
-        const int q = (int)(e % cpr);
+    const long long stride = (long long)gridDim.x * 256;
+    const int dq = (int)(stride % cpr);
+    int q = (int)(((long long)blockIdx.x * 256 + tid) % cpr);   // 8-channel chunk index inside the voxel row
+    for (long long e = (long long)blockIdx.x * 256 + tid; e < total; e += stride, q = (q + dq >= cpr) ? q + dq - cpr : q + dq) {
         const uint4 raw = *reinterpret_cast<const uint4*>(xb + e * 8);
         float f[8], r[8];
         unpack8(raw, f);
         if (rb) unpack8(*reinterpret_cast<const uint4*>(rb + e * 8), r);
+        // per-channel scale / shift / time-bias as 16-byte LDS reads (6 per chunk instead of 24 scalar ones)
+        float sc[8], sh[8], tb[8];
+        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(s_scale + q * 8);
+        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(s_scale + q * 8 + 4);
+        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(s_shift + q * 8);
+        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(s_shift + q * 8 + 4);
+        *reinterpret_cast<float4*>(tb) = *reinterpret_cast<const float4*>(s_tb + q * 8);
+        *reinterpret_cast<float4*>(tb + 4) = *reinterpret_cast<const float4*>(s_tb + q * 8 + 4);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int ch = q * 8 + k;
-            float v = f[k] * s_scale[ch] + s_shift[ch];
+            float v = f[k] * sc[k] + sh[k];
             if (silu_pre) v = silu_f(v);
-            v += s_tb[ch];
+            v += tb[k];
             if (rb) v += r[k];
             if (silu_post) v = silu_f(v);
             f[k] = v;

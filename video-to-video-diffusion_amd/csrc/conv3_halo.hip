@@ -18,10 +18,8 @@
 // Block = 8 waves (4 along M x 2 along N), output tile 4 x 4 x 16 voxels x 128 couts, 64 fp32 accumulators
 // per lane.  Per step = one (kd, kh) pair = 3 taps: 3 weight DMAs + <=1 halo DMA per wave, 48 ds_read_b64,
 // 48 MFMA, one barrier.  Halo tiles are double buffered across chunks, weight slots across steps.
-#include "ctsi_internal.h"
+#include "conv3_halo_common.h"
 #include <string.h>
-
-typedef __attribute__((address_space(3))) void* lptr3_t;
 
 namespace h3 {
 constexpr int TD = 4, TH = 4, TW = 16;
@@ -38,41 +36,6 @@ constexpr int OFF_ROW = OFF_W + 2 * WSLOT_BYTES;
 constexpr int OFF_CS = OFF_ROW + BM * 8;
 constexpr int LDS_BYTES = OFF_CS + 4 * BN * 8;  // column-sum scratch [4][BN][2] floats
 }  // namespace h3
-
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-
-// buffer resource words for a raw (stride 0) byte buffer; every input is wave-uniform
-__device__ __forceinline__ v4i_t h3_make_rsrc(const void* ptr, unsigned num_bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
-    v4i_t r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffull));
-    r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffull));
-    r.z = (int)num_bytes;
-    r.w = 0x00020000;
-    return r;
-}
-
-// One LDS-DMA wave instruction (64 lanes x 16 B -> 1 KiB at `lds_addr`), issued from inline asm so that
-// hipcc does not order later ds_reads behind it with a vmcnt(0): completion is waited for by hand
-// (s_waitcnt vmcnt(0) + s_barrier before the data is read, see the main loop).
-__device__ __forceinline__ void h3_dma16(const v4i_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-        : "memory");
-}
-
-__device__ __forceinline__ int xcd_remap_h(int orig, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + (orig >> 3);
-}
 
 __global__ void __launch_bounds__(512)
 conv3_halo_kernel(const Conv3HaloParams p) {
@@ -350,22 +313,6 @@ conv3_halo_kernel(const Conv3HaloParams p) {
 // instruction count of the 16-wide kernel for the same FLOPs (the 16x16x32 form holds the SIMD's issue
 // port for 8 of its 16 cycles, the 32x32x16 form for 8 of 32), used whenever W >= 32-ish.
 // =====================================================================================================
-namespace h32 {
-constexpr int TD = 4, TH = 2, TW = 32;
-constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
-constexpr int HV = HD * HH * HW;               // 816 halo voxels
-constexpr int HALO_INSTR = (HV + 15) / 16;     // 51
-constexpr int HALO_BYTES = HALO_INSTR * 1024;  // 52224
-constexpr int BM = TD * TH * TW;               // 256
-constexpr int BN = 128;
-constexpr int WSLOT_BYTES = 3 * BN * 64;
-constexpr int NTH = 512;
-constexpr int OFF_W = 2 * HALO_BYTES;
-constexpr int OFF_ROW = OFF_W + 2 * WSLOT_BYTES;
-constexpr int OFF_CS = OFF_ROW + BM * 8;
-constexpr int LDS_BYTES = OFF_CS + 4 * BN * 8;  // 159744 <= 163840
-constexpr int NPIECE = (HALO_INSTR + 7) / 8;   // 7 halo DMA instructions per wave and chunk
-}  // namespace h32
 
 __global__ void __launch_bounds__(512)
 conv3_halo32_kernel(const Conv3HaloParams p) {
@@ -571,6 +518,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
     __syncthreads();
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
+    if (p.dbg & 8) return;
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16 = 64 KB
     const bool want_sums = p.colsum != nullptr;
     const int lhi = lane >> 5, lcol = lane & 31;
@@ -633,7 +581,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
             const int row = c / CPR, ch = c - row * CPR;
             const long long off = s_rowoff[row];
             const int co = n0 + ch * 8;
-            if (off >= 0 && co < p.Cout) {
+            if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
                 const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
                 *reinterpret_cast<uint4*>(y + off + co) = v;
             }

@@ -479,7 +479,8 @@ struct ctsi_conv_plan {
     int8_t pH[4], pW[4];
     int tap_margin[4], ad_min[4];
     int fast, dshift;
-    int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip)
+    int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip);
+                // 3: 4x2x32 tile, persistent blocks (conv3_halo_persist.hip)
     double flops;
 };
 
@@ -672,11 +673,14 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             p->BN = 128;
             const char* hv = getenv("CTSI_CONV_HALO_TILE");   // "16" | "32" (tuning aid)
             if ((padded32 <= padded && !(hv && !strcmp(hv, "16"))) || (hv && !strcmp(hv, "32"))) p->halo3 = 2;
+            // persistent-block variant: measured slower than the one-tile-per-block kernel (its register epilogue
+            // issues 64 two-byte stores per wave, 0.084 ms of a 0.85 ms layer) -> opt-in only, see profiles/r01_notes.md
+            if (p->halo3 == 2 && getenv("CTSI_CONV_PERSIST") && !getenv("CTSI_CONV_NO_PERSIST")) p->halo3 = 3;
         }
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
-    if (p->halo3 == 2) {
+    if (p->halo3 >= 2) {
         p->TD = 4; p->TH = 2; p->TW = 32;
     } else if (p->halo3) {
         p->TD = 4; p->TH = 4; p->TW = 16;
@@ -717,8 +721,13 @@ extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
     if (p->halo3) return (size_t)(p->Cin / 32) * 27 * p->CoutPad * 64;
     return (size_t)p->nclass * p->CoutPad * p->Ktot * 2;
 }
-extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) { return p ? p->nclass * p->mtiles : 0; }
-extern "C" int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* p) { return p ? p->tps : 0; }
+// the persistent halo kernel writes one column-sum row per M-wave (4 per tile)
+extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) {
+    return p ? p->nclass * p->mtiles * (p->halo3 == 3 ? 4 : 1) : 0;
+}
+extern "C" int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* p) {
+    return p ? p->tps * (p->halo3 == 3 ? 4 : 1) : 0;
+}
 extern "C" int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* p) { return p ? p->CoutPad : 0; }
 extern "C" double ctsi_conv_plan_flops(const ctsi_conv_plan* p) { return p ? p->flops : 0.0; }
 extern "C" int ctsi_conv_plan_config(const ctsi_conv_plan* p, int* bm, int* bn, int* mode) {
@@ -830,6 +839,18 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             h.dbg = dbgf ? atoi(dbgf) : 0;
             static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
+        }
+        if (p->halo3 == 3) {
+            static int ncu = 0;
+            if (!ncu) {
+                hipDeviceProp_t prop;
+                int dev = 0;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                    ncu = prop.multiProcessorCount;
+                if (ncu <= 0) ncu = 256;
+            }
+            const char* nb_env = getenv("CTSI_CONV_PERSIST_BLOCKS");   // test aid: force tile switching
+            return ctsi_conv3_halo_persist_launch(&h, nb_env ? atoi(nb_env) : ncu, stream);
         }
         return ctsi_conv3_halo_launch(&h, p->halo3 == 2, stream);
     }

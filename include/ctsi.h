@@ -197,6 +197,14 @@ int ctsi_step_advance(int* step_ptr, void* stream);
 /* x <- nan_to_num(x, nan=0, posinf=1, neginf=-1) on a flat fp32 buffer (model.py:262-341) */
 int ctsi_nan_to_num_f32(float* x, long long count, void* stream);
 
+/* sliding-window stitching (inference/sampler.py:63-172, 338-453): Gaussian-weighted accumulation of one decoded
+ * patch (fp32 NCDHW, nc = batch*channels planes) into the full-volume accumulator and weight map, and the final
+ * acc / (wsum + 1e-8).  wd/wh/ww are the 1-D windows exp(-(x-(n-1)/2)^2 / (2 (n/6)^2)) on the device.          */
+int ctsi_blend_accumulate(float* acc, float* wsum, const float* patch, const float* wd, const float* wh,
+                          const float* ww, int nc, int pd, int ph, int pw, int d_full, int h_full, int w_full,
+                          int d0, int h0, int w0, void* stream);
+int ctsi_blend_normalize(float* acc, const float* wsum, long long count, void* stream);
+
 /* hipMemsetAsync on the engine stream (zeroing GroupNorm accumulators / padded channels);
  * capturable as a memset node.                                                              */
 int ctsi_memset_async(void* ptr, int value, size_t bytes, void* stream);

@@ -298,6 +298,41 @@ def generate(sd: SD, cfg: dict, v_in, sampler: str, n_steps: int, target_depth: 
     return _guard(vae_decode(sd, _guard(z0), sf, "vae."))
 
 
+def gaussian_window(d: int, h: int, w: int):
+    """ref inference/sampler.py:174-198, 455-479"""
+    def ax(n):
+        x = torch.arange(n).float() - (n - 1) / 2
+        return torch.exp(-(x ** 2) / (2 * (n / 6) ** 2))
+    return ax(d)[:, None, None] * ax(h)[None, :, None] * ax(w)[None, None, :]
+
+
+def window_starts(full: int, size: int, stride: int):
+    """ref inference/sampler.py:388-395"""
+    return sorted(set(list(range(0, full - size + 1, stride)) + [max(0, full - size)]))
+
+
+def ddim_stitched(sd: SD, cfg: dict, v_full, n_steps: int, patch, stride, noise_fn: Optional[Callable] = None):
+    """ref inference/sampler.py:338-453 with target_patch_size == patch_size (depth_ratio 1)."""
+    b, c, dt, hf, wf = v_full.shape
+    pd, ph, pw = patch
+    acc = torch.zeros(b, c, dt, hf, wf)
+    wmap = torch.zeros(b, c, dt, hf, wf)
+    win = gaussian_window(pd, ph, pw).view(1, 1, pd, ph, pw)
+    model = lambda z, t, cnd: unet_forward(sd, cfg, z, t, cnd, "unet.")
+    bufs = {k[len("diffusion."):]: v for k, v in sd.items() if k.startswith("diffusion.")}
+    sf = cfg["scaling_factor"]
+    for ds in window_starts(dt, pd, stride[0]):
+        for hs in window_starts(hf, ph, stride[1]):
+            for ws in window_starts(wf, pw, stride[2]):
+                vp = v_full[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw]
+                zc = vae_encode(sd, vp, sf, "vae.")
+                z0 = ddim_sample(model, bufs, tuple(zc.shape), zc, n_steps, noise_fn=noise_fn)
+                out = vae_decode(sd, z0, sf, "vae.")
+                acc[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw] += out * win
+                wmap[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw] += win
+    return acc / (wmap + 1e-8)
+
+
 def psnr(a, b, max_val: float) -> float:
     """ref utils/metrics.py:14-44"""
     mse = torch.clamp(torch.mean((a - b) ** 2), min=1e-8)

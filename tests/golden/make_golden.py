@@ -214,6 +214,22 @@ with torch.no_grad():
         return model.vae.decode(z0)
     out["generate_batch.tiny.out"] = with_injected(gb).numpy()
 
+# 6b. sliding-window stitching (sampler.py:338-453) at depth_ratio == 1 (the only ratio that does not crash
+#     in the reference): every patch's initial draw is the same injected noise (stateless injector)
+with torch.no_grad():
+    v_full = formula_input((1, 1, 6, 24, 24), 17).clamp(-1, 1)
+    orig = torch.randn, torch.randn_like
+    torch.randn = lambda *size, **kw: formula_noise(-1, tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size))
+    torch.randn_like = lambda t, **kw: formula_noise(-1, tuple(t.shape))
+    try:
+        st = DDIMSampler(model.diffusion, model.unet).sample_with_stitching(
+            v_full, model.vae, num_inference_steps=3, patch_size=(4, 16, 16), target_patch_size=(4, 16, 16),
+            stride=(2, 8, 8), device='cpu', progress=False)
+    finally:
+        torch.randn, torch.randn_like = orig
+    out["stitch.tiny.out"] = st.numpy()
+    out["stitch.gauss_4_16_16"] = DDIMSampler(model.diffusion, model.unet)._create_gaussian_weight(4, 16, 16).numpy()
+
 # 7. state-dict layout of the effective production model (names + shapes only, built on `meta`) ----------
 import yaml  # noqa: E402
 cfg_full = yaml.safe_load(open(os.path.join(REF, "config", "slice_interpolation_full_medium.yaml")))

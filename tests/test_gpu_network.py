@@ -192,3 +192,45 @@ def test_config1_patch_size_unet_matches_oracle_on_gpu(pkg):
         ref = R.unet_forward(sd, cfg, x, t, c)
     assert torch.isfinite(out).all()
     assert rel_l2(out.cpu(), ref.cpu()) < NET_TOL
+
+
+def test_sample_with_stitching(golden, pkg):
+    """Sliding-window stitching at depth_ratio 1 (the reference's only working ratio) vs the golden from the
+    reference; blend accumulate / normalise kernels vs a direct torch computation."""
+    model, sd, cfg = tiny_model_sd(pkg)
+    model.to(DEV)
+    v_full = formula_input((1, 1, 6, 24, 24), 17).clamp(-1, 1)
+    sampler = pkg.DDIMSampler(model.diffusion, model.unet)
+    import importlib
+    S = importlib.import_module("video-to-video-diffusion_amd.sampler")
+    out = S._stitched(sampler, v_full, model.vae, (4, 16, 16), (4, 16, 16), (2, 8, 8), DEV, False,
+                      lambda shp, cond: sampler.sample(shp, cond, 3, DEV, progress=False,
+                                                       noise_fn=lambda i, s_: formula_noise(-1, s_)))
+    ref = torch.tensor(golden["stitch.tiny.out"])
+    ref_bf = _bf16_autocast_reference(lambda: R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8),
+                                                              noise_fn=lambda i, s_: formula_noise(-1, s_)))
+    p_hip, p_bf = R.psnr(out.cpu(), ref, 2.0), R.psnr(ref_bf, ref, 2.0)
+    print(f"stitching PSNR vs reference fp32: hip {p_hip:.2f} dB, reference under bf16 autocast {p_bf:.2f} dB")
+    assert tuple(out.shape) == (1, 1, 6, 24, 24) and p_hip >= p_bf - 0.1
+    with pytest.raises(pkg.CtsiError, match="target patch size"):
+        sampler.sample_with_stitching(v_full.to(DEV), model.vae, 3, patch_size=(4, 16, 16),
+                                      target_patch_size=(12, 16, 16), stride=(2, 8, 8), device=DEV, progress=False)
+    # the two blend kernels alone, bit-for-bit against torch
+    E = importlib.import_module("video-to-video-diffusion_amd.engine")
+    ctx = E.Ctx.get(torch.device(DEV))
+    acc = torch.zeros(2, 1, 5, 9, 7, device=DEV)
+    ws = torch.zeros_like(acc)
+    patch = formula_input((2, 1, 3, 4, 5), 3).to(DEV)
+    wd, wh, ww = (S._axis_window(n).to(DEV) for n in (3, 4, 5))
+    with ctx.scope():
+        for (d0, h0, w0) in ((0, 0, 0), (2, 5, 2), (1, 3, 1)):
+            ctx.lib.blend_accumulate(E._ptr(acc), E._ptr(ws), E._ptr(patch), E._ptr(wd), E._ptr(wh), E._ptr(ww), 2, 3, 4, 5,
+                                     5, 9, 7, d0, h0, w0, ctx.sptr)
+        ctx.lib.blend_normalize(E._ptr(acc), E._ptr(ws), acc.numel(), ctx.sptr)
+    torch.cuda.synchronize()
+    win = S.gaussian_weight(3, 4, 5)
+    a2, w2 = torch.zeros(2, 1, 5, 9, 7), torch.zeros(2, 1, 5, 9, 7)
+    for (d0, h0, w0) in ((0, 0, 0), (2, 5, 2), (1, 3, 1)):
+        a2[:, :, d0:d0 + 3, h0:h0 + 4, w0:w0 + 5] += patch.cpu() * win
+        w2[:, :, d0:d0 + 3, h0:h0 + 4, w0:w0 + 5] += win
+    assert torch.allclose(acc.cpu(), a2 / (w2 + 1e-8), rtol=1e-6, atol=1e-7)

@@ -180,3 +180,12 @@ def test_generate_end_to_end(golden, pkg):
     z0 = R.ddim_sample(model, R.diffusion_buffers(), tuple(z_in.shape), z_in, 5, noise_fn=formula_noise)
     outb = R.vae_decode(sd, z0, 1.0, "vae.")
     assert R.psnr(outb, torch.tensor(golden["generate_batch.tiny.out"]), 2.0) > 80.0
+
+
+def test_stitching_depth_ratio_one(golden, pkg):
+    _, sd, cfg = tiny_model_sd(pkg)
+    v_full = formula_input((1, 1, 6, 24, 24), 17).clamp(-1, 1)
+    assert torch.allclose(R.gaussian_window(4, 16, 16), torch.tensor(golden["stitch.gauss_4_16_16"]))
+    assert R.window_starts(24, 16, 8) == [0, 8] and R.window_starts(6, 4, 2) == [0, 2]
+    out = R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8), noise_fn=lambda i, shp: formula_noise(-1, shp))
+    assert R.psnr(out, torch.tensor(golden["stitch.tiny.out"]), 2.0) > 80.0

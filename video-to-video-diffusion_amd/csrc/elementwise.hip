@@ -311,3 +311,53 @@ extern "C" int ctsi_nan_to_num_f32(float* x, long long count, void* stream) {
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }
+
+// ---- sliding-window stitching (inference/sampler.py:157-170, 438-451) ------------------------------------------
+// acc[.., d0+d, h0+h, w0+w] += patch[.., d, h, w] * wd[d]*wh[h]*ww[w];  wsum[...] += wd*wh*ww   (fp32 NCDHW)
+// One launch per patch (patches are produced one after the other), 1-D separable Gaussian windows.
+__global__ void __launch_bounds__(256)
+blend_accumulate_kernel(float* __restrict__ acc, float* __restrict__ wsum, const float* __restrict__ patch,
+                        const float* __restrict__ wd, const float* __restrict__ wh, const float* __restrict__ ww,
+                        int nc, int pd, int ph, int pw, int D, int H, int W, int d0, int h0, int w0, long long total) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int w = (int)(e % pw);
+        long long r = e / pw;
+        const int h = (int)(r % ph);
+        r /= ph;
+        const int d = (int)(r % pd);
+        const long long c = r / pd;
+        const float g = wd[d] * wh[h] * ww[w];
+        const long long o = ((c * D + d0 + d) * H + h0 + h) * W + w0 + w;
+        acc[o] += patch[e] * g;
+        wsum[o] += g;
+    }
+}
+extern "C" int ctsi_blend_accumulate(float* acc, float* wsum, const float* patch, const float* wd, const float* wh,
+                                     const float* ww, int nc, int pd, int ph, int pw, int d_full, int h_full,
+                                     int w_full, int d0, int h0, int w0, void* stream) {
+    CTSI_CHECK_ARG(acc && wsum && patch && wd && wh && ww, "ctsi_blend_accumulate: null argument");
+    CTSI_CHECK_ARG(d0 >= 0 && h0 >= 0 && w0 >= 0 && d0 + pd <= d_full && h0 + ph <= h_full && w0 + pw <= w_full,
+                   "ctsi_blend_accumulate: patch (%d,%d,%d)+(%d,%d,%d) outside the volume (%d,%d,%d)", d0, h0, w0, pd, ph,
+                   pw, d_full, h_full, w_full);
+    const long long total = (long long)nc * pd * ph * pw;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(blend_accumulate_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, acc, wsum,
+                       patch, wd, wh, ww, nc, pd, ph, pw, d_full, h_full, w_full, d0, h0, w0, total);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+__global__ void __launch_bounds__(256) blend_normalize_kernel(float* acc, const float* wsum, long long count) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256)
+        acc[e] = acc[e] / (wsum[e] + 1e-8f);
+}
+extern "C" int ctsi_blend_normalize(float* acc, const float* wsum, long long count, void* stream) {
+    CTSI_CHECK_ARG(acc && wsum && count >= 0, "ctsi_blend_normalize: bad arguments");
+    if (count == 0) return CTSI_OK;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(blend_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, acc, wsum, count);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}

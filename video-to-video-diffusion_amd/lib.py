@@ -87,6 +87,8 @@ SIGNATURES = {
     "ctsi_ddpm_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_step_advance": (_i, [_vp, _vp], True),
     "ctsi_nan_to_num_f32": (_i, [_vp, _ll, _vp], True),
+    "ctsi_blend_accumulate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], True),
+    "ctsi_blend_normalize": (_i, [_vp, _vp, _ll, _vp], True),
     "ctsi_memset_async": (_i, [_vp, _i, _sz, _vp], True),
     "ctsi_graph_begin_capture": (_i, [_vp], True),
     "ctsi_graph_end_capture": (_i, [_vp, C.POINTER(_vp)], True),

@@ -210,43 +210,65 @@ class DDIMSampler:
 
 def gaussian_weight(d: int, h: int, w: int) -> torch.Tensor:
     """Separable blend window, sigma = size/6, centred at (n-1)/2 (sampler.py:174-198)."""
-    def axis(n):
-        x = torch.arange(n).float() - (n - 1) / 2
-        return torch.exp(-(x ** 2) / (2 * (n / 6) ** 2))
-    return axis(d)[:, None, None] * axis(h)[None, :, None] * axis(w)[None, None, :]
+    return _axis_window(d)[:, None, None] * _axis_window(h)[None, :, None] * _axis_window(w)[None, None, :]
 
 
 def _window_starts(full: int, size: int, step: int):
     return sorted(set(list(range(0, full - size + 1, step)) + [max(0, full - size)]))
 
 
+def _axis_window(n: int) -> torch.Tensor:
+    x = torch.arange(n).float() - (n - 1) / 2
+    return torch.exp(-(x ** 2) / (2 * (n / 6) ** 2))
+
+
 def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride, device, progress, sample_fn):
-    """Sliding-window inference (sampler.py:63-172, 338-453).  As in the reference, the latent is
-    sampled at the *thick* patch depth, so only depth_ratio == 1 is meaningful; other ratios fail in
-    the reference with a shape error and are rejected here up front."""
+    """Sliding-window inference (sampler.py:63-172, 338-453): per window encode -> sample -> decode on the
+    engine, Gaussian-weighted accumulation (ctsi_blend_accumulate) and final normalisation
+    (ctsi_blend_normalize) on device.  As in the reference, the latent is sampled at the *thick* patch depth,
+    so only depth_ratio == 1 is meaningful; other ratios fail in the reference with a shape error and are
+    rejected here up front.  Under torch.distributed the windows are data-parallel units (parallel.shard_units):
+    every rank blends its share and the accumulators are all-reduced before normalisation."""
     b, c, d_thick, hf, wf = v_thick_full.shape
     pd, ph, pw = patch_size
     td, th, tw = target_patch_size
-    ratio = td / pd
-    if td != pd:
-        raise CtsiError("sample_with_stitching: target depth != patch depth is unsupported (the reference "
+    if (td, th, tw) != (pd, ph, pw):
+        raise CtsiError("sample_with_stitching: target patch size != patch size is unsupported (the reference "
                         "implementation raises a shape mismatch in this case; use generate(target_depth=...))")
-    d_thin = int(d_thick * ratio)
     dev = torch.device(device)
-    acc = torch.zeros(b, c, d_thin, hf, wf, device=dev)
-    wsum = torch.zeros(b, c, d_thin, hf, wf, device=dev)
-    win = gaussian_weight(td, th, tw).to(dev).view(1, 1, td, th, tw)
-    for ds in _window_starts(d_thick, pd, stride[0]):
-        for hs in _window_starts(hf, ph, stride[1]):
-            for ws in _window_starts(wf, pw, stride[2]):
-                patch = v_thick_full[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw].to(dev)
-                z_cond = vae.encode(patch)
-                z = sample_fn(tuple(z_cond.shape), z_cond)
-                out = vae.decode(z)
-                d0 = int(ds * ratio)
-                acc[:, :, d0:d0 + td, hs:hs + th, ws:ws + tw] += out * win
-                wsum[:, :, d0:d0 + td, hs:hs + th, ws:ws + tw] += win
-    return acc / (wsum + 1e-8)
+    ctx = Ctx.get(dev)
+    lib, sptr = ctx.lib, ctx.sptr
+    acc = torch.zeros(b, c, d_thick, hf, wf, device=ctx.device)
+    wsum = torch.zeros(b, c, d_thick, hf, wf, device=ctx.device)
+    wd, wh, ww = (_axis_window(n).to(ctx.device) for n in (td, th, tw))
+    windows = [(ds, hs, ws) for ds in _window_starts(d_thick, pd, stride[0])
+               for hs in _window_starts(hf, ph, stride[1]) for ws in _window_starts(wf, pw, stride[2])]
+    rank, world = 0, 1
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+    except Exception:  # pragma: no cover
+        dist = None
+    from .parallel import shard_units
+    mine = [windows[i] for i in shard_units(len(windows), rank, world)]
+    it = mine
+    if progress and tqdm is not None:
+        it = tqdm(mine, desc="Patch-based inference", total=len(mine))
+    for (ds, hs, ws) in it:
+        patch = v_thick_full[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw].to(ctx.device).contiguous()
+        z_cond = vae.encode(patch)
+        z = sample_fn(tuple(z_cond.shape), z_cond)
+        out = vae.decode(z).contiguous()
+        with ctx.scope():
+            lib.blend_accumulate(_ptr(acc), _ptr(wsum), _ptr(out), _ptr(wd), _ptr(wh), _ptr(ww), b * c, td, th, tw,
+                                 d_thick, hf, wf, ds, hs, ws, sptr)
+    if world > 1:
+        dist.all_reduce(acc)
+        dist.all_reduce(wsum)
+    with ctx.scope():
+        lib.blend_normalize(_ptr(acc), _ptr(wsum), acc.numel(), sptr)
+    return acc
 
 
 class EDMSampler:

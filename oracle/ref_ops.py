@@ -311,13 +311,19 @@ def window_starts(full: int, size: int, stride: int):
     return sorted(set(list(range(0, full - size + 1, stride)) + [max(0, full - size)]))
 
 
-def ddim_stitched(sd: SD, cfg: dict, v_full, n_steps: int, patch, stride, noise_fn: Optional[Callable] = None):
-    """ref inference/sampler.py:338-453 with target_patch_size == patch_size (depth_ratio 1)."""
+def ddim_stitched(sd: SD, cfg: dict, v_full, n_steps: int, patch, stride, noise_fn: Optional[Callable] = None,
+                  target_d: Optional[int] = None):
+    """ref inference/sampler.py:338-453.  target_d == patch depth (default) follows the reference line by line
+    and is pinned by golden 'stitch.tiny.out'.  target_d != patch depth is the *intended* behaviour (the
+    reference raises a shape error there): the window's conditioning latent is upsampled along depth the way
+    models/model.py:284-289 does for whole volumes; unpinned by the reference."""
     b, c, dt, hf, wf = v_full.shape
     pd, ph, pw = patch
-    acc = torch.zeros(b, c, dt, hf, wf)
-    wmap = torch.zeros(b, c, dt, hf, wf)
-    win = gaussian_window(pd, ph, pw).view(1, 1, pd, ph, pw)
+    td = pd if target_d is None else int(target_d)
+    ratio = td / pd
+    acc = torch.zeros(b, c, int(dt * ratio), hf, wf)
+    wmap = torch.zeros_like(acc)
+    win = gaussian_window(td, ph, pw).view(1, 1, td, ph, pw)
     model = lambda z, t, cnd: unet_forward(sd, cfg, z, t, cnd, "unet.")
     bufs = {k[len("diffusion."):]: v for k, v in sd.items() if k.startswith("diffusion.")}
     sf = cfg["scaling_factor"]
@@ -326,10 +332,13 @@ def ddim_stitched(sd: SD, cfg: dict, v_full, n_steps: int, patch, stride, noise_
             for ws in window_starts(wf, pw, stride[2]):
                 vp = v_full[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw]
                 zc = vae_encode(sd, vp, sf, "vae.")
+                if td != pd:
+                    zc = trilinear_depth(zc, td)
                 z0 = ddim_sample(model, bufs, tuple(zc.shape), zc, n_steps, noise_fn=noise_fn)
                 out = vae_decode(sd, z0, sf, "vae.")
-                acc[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw] += out * win
-                wmap[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw] += win
+                d0 = int(ds * ratio)
+                acc[:, :, d0:d0 + td, hs:hs + ph, ws:ws + pw] += out * win
+                wmap[:, :, d0:d0 + td, hs:hs + ph, ws:ws + pw] += win
     return acc / (wmap + 1e-8)
 
 

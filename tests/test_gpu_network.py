@@ -212,9 +212,22 @@ def test_sample_with_stitching(golden, pkg):
     p_hip, p_bf = R.psnr(out.cpu(), ref, 2.0), R.psnr(ref_bf, ref, 2.0)
     print(f"stitching PSNR vs reference fp32: hip {p_hip:.2f} dB, reference under bf16 autocast {p_bf:.2f} dB")
     assert tuple(out.shape) == (1, 1, 6, 24, 24) and p_hip >= p_bf - 0.1
-    with pytest.raises(pkg.CtsiError, match="target patch size"):
+    with pytest.raises(pkg.CtsiError, match="must equal the thick patch"):
         sampler.sample_with_stitching(v_full.to(DEV), model.vae, 3, patch_size=(4, 16, 16),
-                                      target_patch_size=(12, 16, 16), stride=(2, 8, 8), device=DEV, progress=False)
+                                      target_patch_size=(12, 8, 16), stride=(2, 8, 8), device=DEV, progress=False)
+    # depth_ratio 3 (the reference raises a shape error here; intended behaviour = per-window depth upsample of
+    # the conditioning latent, checked against the oracle's restatement of that intent)
+    nf = lambda i, s_: formula_noise(-1, s_)
+    out3 = S._stitched(sampler, v_full, model.vae, (4, 16, 16), (12, 16, 16), (2, 8, 8), DEV, False,
+                       lambda shp, cond: sampler.sample(shp, cond, 3, DEV, progress=False, noise_fn=nf))
+    ref3 = R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8), noise_fn=nf, target_d=12)
+    ref3_bf = _bf16_autocast_reference(lambda: R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8),
+                                                               noise_fn=nf, target_d=12))
+    p3, p3_bf = R.psnr(out3.cpu(), ref3, 2.0), R.psnr(ref3_bf, ref3, 2.0)
+    print(f"stitching depth_ratio 3 PSNR vs oracle fp32: hip {p3:.2f} dB, oracle under bf16 autocast {p3_bf:.2f} dB")
+    # two different bf16 rounding realisations of a chaotic 3-step, random-weight pipeline: their PSNRs scatter
+    # by a few tenths of a dB around each other (measured 27.79 vs 27.97), hence 0.5 dB here, not 0.1
+    assert tuple(out3.shape) == (1, 1, 18, 24, 24) and p3 >= p3_bf - 0.5
     # the two blend kernels alone, bit-for-bit against torch
     E = importlib.import_module("video-to-video-diffusion_amd.engine")
     ctx = E.Ctx.get(torch.device(DEV))

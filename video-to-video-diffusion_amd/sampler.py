@@ -15,7 +15,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .engine import Ctx, UNetProgram, _ptr, nan_to_num_
+from .engine import Ctx, UNetProgram, _ptr, nan_to_num_, trilinear_depth
 from .lib import CtsiError
 
 logger = logging.getLogger(__name__)
@@ -225,21 +225,29 @@ def _axis_window(n: int) -> torch.Tensor:
 def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride, device, progress, sample_fn):
     """Sliding-window inference (sampler.py:63-172, 338-453): per window encode -> sample -> decode on the
     engine, Gaussian-weighted accumulation (ctsi_blend_accumulate) and final normalisation
-    (ctsi_blend_normalize) on device.  As in the reference, the latent is sampled at the *thick* patch depth,
-    so only depth_ratio == 1 is meaningful; other ratios fail in the reference with a shape error and are
-    rejected here up front.  Under torch.distributed the windows are data-parallel units (parallel.shard_units):
-    every rank blends its share and the accumulators are all-reduced before normalisation."""
+    (ctsi_blend_normalize) on device.
+
+    depth_ratio == 1 reproduces the reference exactly (pinned by tests/golden 'stitch.tiny.out').  For
+    depth_ratio != 1 the reference samples the latent at the *thick* patch depth and then fails with a shape
+    mismatch when it adds the decoded patch to the thin accumulator; here the window's
+    conditioning latent is upsampled along depth to the target depth first, exactly as
+    VideoToVideoDiffusion.generate does for a whole volume (models/model.py:284-289), so every window
+    produces a (target_d, h, w) patch that lands at depth int(d_start * depth_ratio).
+    Under torch.distributed the windows are data-parallel units (parallel.shard_units): every rank blends
+    its share and the accumulators are all-reduced before normalisation."""
     b, c, d_thick, hf, wf = v_thick_full.shape
     pd, ph, pw = patch_size
     td, th, tw = target_patch_size
-    if (td, th, tw) != (pd, ph, pw):
-        raise CtsiError("sample_with_stitching: target patch size != patch size is unsupported (the reference "
-                        "implementation raises a shape mismatch in this case; use generate(target_depth=...))")
+    if (th, tw) != (ph, pw):
+        raise CtsiError(f"sample_with_stitching: target patch (h, w)=({th},{tw}) must equal the thick patch "
+                        f"(h, w)=({ph},{pw}); only depth is interpolated")
+    ratio = td / pd
+    d_thin = int(d_thick * ratio)
     dev = torch.device(device)
     ctx = Ctx.get(dev)
     lib, sptr = ctx.lib, ctx.sptr
-    acc = torch.zeros(b, c, d_thick, hf, wf, device=ctx.device)
-    wsum = torch.zeros(b, c, d_thick, hf, wf, device=ctx.device)
+    acc = torch.zeros(b, c, d_thin, hf, wf, device=ctx.device)
+    wsum = torch.zeros(b, c, d_thin, hf, wf, device=ctx.device)
     wd, wh, ww = (_axis_window(n).to(ctx.device) for n in (td, th, tw))
     windows = [(ds, hs, ws) for ds in _window_starts(d_thick, pd, stride[0])
                for hs in _window_starts(hf, ph, stride[1]) for ws in _window_starts(wf, pw, stride[2])]
@@ -258,11 +266,14 @@ def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride,
     for (ds, hs, ws) in it:
         patch = v_thick_full[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw].to(ctx.device).contiguous()
         z_cond = vae.encode(patch)
+        if td != pd:
+            with ctx.scope():
+                z_cond = trilinear_depth(ctx, z_cond, td)
         z = sample_fn(tuple(z_cond.shape), z_cond)
         out = vae.decode(z).contiguous()
         with ctx.scope():
             lib.blend_accumulate(_ptr(acc), _ptr(wsum), _ptr(out), _ptr(wd), _ptr(wh), _ptr(ww), b * c, td, th, tw,
-                                 d_thick, hf, wf, ds, hs, ws, sptr)
+                                 d_thin, hf, wf, int(ds * ratio), hs, ws, sptr)
     if world > 1:
         dist.all_reduce(acc)
         dist.all_reduce(wsum)

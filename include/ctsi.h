@@ -197,6 +197,77 @@ int ctsi_step_advance(int* step_ptr, void* stream);
 /* x <- nan_to_num(x, nan=0, posinf=1, neginf=-1) on a flat fp32 buffer (model.py:262-341) */
 int ctsi_nan_to_num_f32(float* x, long long count, void* stream);
 
+/* ---- training path (models/diffusion.py:81-247, models/model.py:158-228; backward = what autograd derives) ---- */
+/* Weight gradient of Conv3d / ConvTranspose3d:  dw[cr*stride_r + cg*stride_g + t*stride_t] =
+ *   scale * sum_v R[v][cr] * G[map(v,t)][cg],  map(v,t) = (n, d-pd+kd, h*sh-ph+kh, w*sw-pw+kw), zero outside G.
+ * Conv3d: R = grad of the output, G = layer input (weight (cout,cin,kd,kh,kw): stride_r = cin*T, stride_g = T,
+ * stride_t = 1).  ConvTranspose3d: R = layer input, G = grad of the output (weight (cin,cout,kd,kh,kw)).
+ * bf16 NDHWC tensors, channel counts multiples of 8; a concatenated input is two calls with dw offset by the
+ * first source's channels.  Deterministic (split-K partials in `workspace`, summed in a fixed order). */
+typedef struct ctsi_wgrad_desc {
+    int kd, kh, kw;
+    int sh, sw;
+    int pd, ph, pw;
+    int n;
+    int dr, hr, wr;        /* spatial size of R */
+    int dg, hg, wg;        /* spatial size of G */
+    int cr, cr_stride;     /* channels of R used / channels per voxel of R */
+    int cg, cg_stride;
+} ctsi_wgrad_desc;
+size_t ctsi_wgrad_workspace_bytes(const ctsi_wgrad_desc* desc);
+double ctsi_wgrad_flops(const ctsi_wgrad_desc* desc);
+int ctsi_wgrad(const ctsi_wgrad_desc* desc, const void* r, const void* g, void* workspace, float* dw,
+               long long stride_r, long long stride_g, long long stride_t, float scale, void* stream);
+
+/* out (ci_cnt, cout, T) with out[ci'][co][T-1-t] = w[co][ci_off+ci'][t]: the weight of the stride-1 'same' Conv3d
+ * that computes the data gradient of a stride-1 'same' Conv3d with weight w (cout, cin, T) for the input-channel
+ * slice [ci_off, ci_off+ci_cnt).  (Strided Conv3d <-> ConvTranspose3d data gradients use the weights as they are.) */
+int ctsi_weight_dgrad_layout(const float* w, float* out, int cout, int cin, int taps, int ci_off, int ci_cnt,
+                             void* stream);
+
+/* Backward of ctsi_gn_apply (GroupNorm [+SiLU] [+time bias] [+residual] [+SiLU]).  x: the tensor that was normalised,
+ * dy: gradient of the output (depth-broadcast (n,1,h,w,c) tensor when dy_bcast_d), sums: the forward's fp64 statistics,
+ * residual: the forward's residual input (needed when silu_post).  Writes g_buf = gradient of the GroupNorm output
+ * (== gradient of the residual when !silu_pre), dx (+ add when given), dgamma/dbeta (c floats) and, when dtbias is
+ * given, dtbias[n][c] (row stride dtbias_stride) = per-sample channel sums of the gradient after the outer SiLU.
+ * workspace: ctsi_gn_bwd_workspace_floats() floats. */
+int ctsi_gn_bwd_tiles(int d, int h, int w);
+size_t ctsi_gn_bwd_workspace_floats(int n, int c, int d, int h, int w, int groups);
+int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const double* sums, const float* gamma,
+                const float* beta, int n, int c, int d, int h, int w, int groups, float eps, int silu_pre,
+                const void* residual, int silu_post, const void* add, void* g_buf, void* dx, float* workspace,
+                float* dgamma, float* dbeta, float* dtbias, long long dtbias_stride, void* stream);
+
+/* out[c] = scale * sum over rows of x[row][c]  (bf16 rows of c_stride channels; conv bias gradients) */
+size_t ctsi_channel_sum_workspace_floats(long long rows, int c);
+int ctsi_channel_sum(const void* x, long long rows, int c, int c_stride, float* workspace, float* out, float scale,
+                     void* stream);
+int ctsi_add_bf16(void* a, const void* b, long long count, void* stream);        /* a += b */
+int ctsi_f32_to_bf16(const float* src, void* dst, long long count, void* stream);
+
+/* q_sample (models/diffusion.py:81-106): z_t = sqrt_alphas_cumprod[t_b]*z0 + sqrt_one_minus_alphas_cumprod[t_b]*noise,
+ * fp32 NCDHW in, bf16 NDHWC channel slice out (the U-Net input tensor [z_t | cond]). */
+int ctsi_q_sample(const float* z0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, const int* t,
+                  void* dst, int n, int c, int d, int h, int w, int c_total, int c_off, void* stream);
+/* Min-SNR weighted MSE (models/diffusion.py:147-203): loss_out[0] = sum_b norm[b] * sum mask*(pred-noise)^2,
+ * loss_out[1+b] = per-sample sums.  pred fp32 NDHWC, noise fp32 NCDHW, mask fp32 (n,c,d) or NULL; the caller folds the
+ * SNR weight and the normalisation of the reference's three cases into norm[b].  _bwd writes
+ * d_pred = 2*norm[b]*mask*(pred-noise)*gscale[0] as bf16 NDHWC with c_stride channels per voxel (extra ones zero). */
+size_t ctsi_mse_loss_workspace_doubles(int n);
+int ctsi_mse_loss_fwd(const float* pred, const float* noise, const float* mask, const float* norm, int n, int c,
+                      int d, int h, int w, double* workspace, float* loss_out, void* stream);
+int ctsi_mse_loss_bwd(const float* pred, const float* noise, const float* mask, const float* norm,
+                      const float* gscale, int n, int c, int d, int h, int w, void* dpred, int c_stride, void* stream);
+
+/* time embedding for training: as ctsi_time_embed_fwd, but scratch = [sincos | first Linear PRE-activation | temb] */
+int ctsi_time_embed_train_fwd(const int* t_rows, int rows, int dim, int time_dim, const float* w1, const float* b1,
+                              const float* w2, const float* b2, const float* w_all, const float* b_all,
+                              int total_out, float* scratch, float* tbias_out, void* stream);
+/* backward of y = act(x) W^T + b (act = SiLU when silu_in, x then is the pre-activation); rows <= 64; any of
+ * dw/db/dx may be NULL */
+int ctsi_linear_bwd(const float* x, const float* w, const float* dy, int rows, int in_dim, int out_dim, int silu_in,
+                    float* dw, float* db, float* dx, void* stream);
+
 /* sliding-window stitching (inference/sampler.py:63-172, 338-453): Gaussian-weighted accumulation of one decoded
  * patch (fp32 NCDHW, nc = batch*channels planes) into the full-volume accumulator and weight map, and the final
  * acc / (wsum + 1e-8).  wd/wh/ww are the 1-D windows exp(-(x-(n-1)/2)^2 / (2 (n/6)^2)) on the device.          */

@@ -1,0 +1,298 @@
+// Weight gradient of Conv3d / ConvTranspose3d on NDHWC bf16 tensors (gfx950 / MI355X).
+//
+//   dW[t][cr][cg] = sum over row voxels v of  R[v][cr] * G[map(v, t)][cg]
+//
+// R is the tensor that lives on the layer's *small/output-side* grid and G the one that is gathered
+// with the tap shift (and the H/W stride):
+//   Conv3d          : R = dL/dy (output grid),       G = layer input x,     dW -> weight[cout][cin][t]
+//   ConvTranspose3d : R = layer input (small grid),  G = dL/dy (big grid),  dW -> weight[cin][cout][t]
+// map(v, t) = (n, d - pd + kd, h*sh - ph + kh, w*sw - pw + kw); out-of-volume taps contribute zero.
+//
+// GEMM view: M = R channels, N = G channels, K = voxels.  Both operands sit in memory as
+// [voxel][channel] (k-major), i.e. transposed with respect to what the MFMA operand registers want
+// (8 consecutive k per lane).  The slabs are therefore staged as they are ([32 voxels][128 ch], 256-byte
+// rows, LDS-DMA with the tap shift / zero fill done by the per-lane source address) and read with
+// gfx950's transposing LDS read ds_read_b64_tr_b16: a 16-lane group fetches a 4-voxel x 16-channel block
+// and every lane receives its channel's 4 consecutive voxels.  Row image: chunk16 ^= ((row&3)<<2)|((row>>2)&3)
+// (conflict-free for the 32x32x16 transposed reads), applied on the DMA source side.
+//
+// Block = 4 waves, tile 128 (R ch) x 128 (G ch) for ONE tap over a slice of the voxel range (split-K);
+// partial tiles go to a workspace [slice][tap][CRpad][CGpad] fp32 and a second kernel sums the slices in a
+// fixed order into the PyTorch weight-gradient layout (deterministic, no atomics).
+#include "conv3_halo_common.h"
+
+namespace wgk {
+constexpr int BR = 128, BG = 128, BK = 32, NTH = 256;
+constexpr int SLAB = BK * 256;     // 8 KB: [32 voxels][128 ch] bf16
+constexpr int STAGE = 2 * SLAB;    // R slab, G slab
+constexpr int LDS_BYTES = 2 * STAGE;
+}  // namespace wgk
+
+struct WgradParams {
+    const bf16_t* R;
+    const bf16_t* G;
+    float* part;
+    unsigned r_bytes, g_bytes;
+    int CR, CRs, CG, CGs;
+    int N, Dr, Hr, Wr, Dg, Hg, Wg;
+    int KH, KW, sh, sw, pd, ph, pw;
+    int T, tiles_r, tiles_g, S, ksteps, kps;
+    int V;  // row voxels (< 2^31)
+    unsigned mW, mH, mD;
+    int shW, shH, shD;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+__device__ __forceinline__ unsigned wg_div(unsigned v, unsigned m, int sh) {
+    return (unsigned)(((unsigned long long)v * m) >> sh);
+}
+
+__device__ __forceinline__ s16x4 wg_tr_read(unsigned lds_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(unsigned long long)lds_addr);
+}
+
+__global__ void __launch_bounds__(256)
+conv_wgrad_kernel(const WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace wgk;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- block decode: tap fastest (neighbouring blocks share both slabs in L2), then tiles, then slice ----
+    int bid = blockIdx.x;
+    const int t = bid % p.T;
+    bid /= p.T;
+    const int tg = bid % p.tiles_g;
+    bid /= p.tiles_g;
+    const int tr = bid % p.tiles_r;
+    const int sl = bid / p.tiles_r;
+    const int kd = t / (p.KH * p.KW);
+    const int kh = (t / p.KW) % p.KH;
+    const int kw = t % p.KW;
+    const int k_begin = sl * p.kps;
+    const int k_end = min(k_begin + p.kps, p.ksteps);
+
+    const v4i_t rsR = h3_make_rsrc(p.R, p.r_bytes);
+    const v4i_t rsG = h3_make_rsrc(p.G, p.g_bytes);
+
+    // ---- per-lane staging constants: this lane fills LDS rows rl[j] = 8*wv + 4*j + lane/16, slot lane%16 ----
+    unsigned r_col[2], g_col[2];
+    bool r_ok[2], g_ok[2];
+    int rl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        rl[j] = 8 * wv + 4 * j + (lane >> 4);
+        const int f = ((rl[j] & 3) << 2) | ((rl[j] >> 2) & 3);
+        const int ch = (lane & 15) ^ f;
+        const int cr = tr * BR + ch * 8, cg = tg * BG + ch * 8;
+        r_ok[j] = cr < p.CR;
+        g_ok[j] = cg < p.CG;
+        r_col[j] = (unsigned)cr * 2u;
+        g_col[j] = (unsigned)cg * 2u;
+    }
+
+    auto issue = [&](int ks, int stage) {
+        const unsigned base = lds0 + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned v = (unsigned)ks * BK + rl[j];
+            const bool vin = v < (unsigned)p.V;
+            // row tensor: linear voxel index
+            const unsigned roff = (vin && r_ok[j]) ? v * (unsigned)(p.CRs * 2) + r_col[j] : 0xffffffffu;
+            h3_dma16(rsR, base + (8 * wv + 4 * j) * 256, roff, 0);
+            // gathered tensor: decode (n, d, h, w), apply the tap
+            const unsigned q1 = wg_div(v, p.mW, p.shW);
+            const int w = (int)(v - q1 * p.Wr);
+            const unsigned q2 = wg_div(q1, p.mH, p.shH);
+            const int h = (int)(q1 - q2 * p.Hr);
+            const unsigned nn = wg_div(q2, p.mD, p.shD);
+            const int d = (int)(q2 - nn * p.Dr);
+            const int gd = d - p.pd + kd, gh = h * p.sh - p.ph + kh, gw = w * p.sw - p.pw + kw;
+            const bool ok = vin && g_ok[j] && (unsigned)gd < (unsigned)p.Dg && (unsigned)gh < (unsigned)p.Hg &&
+                            (unsigned)gw < (unsigned)p.Wg;
+            const unsigned gvox = ((nn * p.Dg + gd) * p.Hg + gh) * p.Wg + gw;
+            const unsigned goff = ok ? gvox * (unsigned)(p.CGs * 2) + g_col[j] : 0xffffffffu;
+            h3_dma16(rsG, base + SLAB + (8 * wv + 4 * j) * 256, goff, 0);
+        }
+    };
+
+    // ---- per-lane transposed-read offsets (bytes inside a slab, k-substep 0) ----------------------------------
+    // operand tile with channel base 32*ct: lane reads rows 8*(lane>>5) + 4e + q (q = (lane&15)>>2),
+    // 16-byte chunk 4*ct + 2*((lane>>4)&1) + (p>>1) (p = lane&3), + 8*(p&1) bytes.
+    const int wr = wv >> 1, wgc = wv & 1;
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    unsigned a_off[2][2], b_off[2][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = 8 * (lane >> 5) + 4 * e + q;
+        const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cha = 4 * (2 * wr + i) + 2 * ((lane >> 4) & 1) + (pp >> 1);
+            const int chb = 4 * (2 * wgc + i) + 2 * ((lane >> 4) & 1) + (pp >> 1);
+            a_off[i][e] = (unsigned)(256 * row + 16 * (cha ^ f) + 8 * (pp & 1));
+            b_off[i][e] = (unsigned)(SLAB + 256 * row + 16 * (chb ^ f) + 8 * (pp & 1));
+        }
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (k_begin < k_end) {
+        issue(k_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int ks = k_begin; ks < k_end; ++ks) {
+            const int stage = (ks - k_begin) & 1;
+            if (ks + 1 < k_end) issue(ks + 1, stage ^ 1);
+            const unsigned sb = lds0 + stage * STAGE;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const unsigned so = sb + sub * (16 * 256);   // rows 16*sub ...: the swizzle only sees row % 16
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const s16x4 a0 = wg_tr_read(so + a_off[i][0]);
+                    const s16x4 a1 = wg_tr_read(so + a_off[i][1]);
+                    const s16x4 b0 = wg_tr_read(so + b_off[i][0]);
+                    const s16x4 b1 = wg_tr_read(so + b_off[i][1]);
+                    af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bfr[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---- partial tile -> workspace [slice][tap][CRpad][CGpad] ------------------------------------------------
+    const int CRp = p.tiles_r * BR, CGp = p.tiles_g * BG;
+    float* dst = p.part + ((size_t)sl * p.T + t) * (size_t)CRp * CGp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cg = tg * BG + 64 * wgc + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = tr * BR + 64 * wr + 32 * i + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                dst[(size_t)cr * CGp + cg] = acc[i][j][r];
+            }
+        }
+#endif
+}
+
+// dw[cr*sr + cg*sg + t*st] = sum_s part[s][t][cr][cg]        (fixed summation order)
+__global__ void __launch_bounds__(256)
+conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T, int CRp, int CGp,
+                         int CR, int CG, long long sr, long long sg, long long st, float scale) {
+    const long long total = (long long)CR * CG;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int cr = (int)(e / CG), cg = (int)(e - (long long)cr * CG);
+        for (int t = 0; t < T; ++t) {
+            float s = 0.0f;
+            for (int k = 0; k < S; ++k) s += part[(((size_t)k * T + t) * CRp + cr) * CGp + cg];
+            dw[cr * sr + cg * sg + t * st] = s * scale;
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+static void wg_magic(unsigned d, unsigned* m, int* sh) {
+    int s = 0;
+    while ((1ull << s) < d) ++s;
+    *m = (unsigned)(((1ull << (31 + s)) / d) + 1ull);
+    *sh = 31 + s;
+}
+
+struct WgradGeom {
+    int T, tiles_r, tiles_g, S, ksteps, kps;
+    long long V;
+};
+
+static int wg_geometry(const ctsi_wgrad_desc* d, WgradGeom* g) {
+    CTSI_CHECK_ARG(d && d->kd > 0 && d->kh > 0 && d->kw > 0 && d->sh > 0 && d->sw > 0, "ctsi_wgrad: bad kernel/stride");
+    CTSI_CHECK_ARG(d->n > 0 && d->dr > 0 && d->hr > 0 && d->wr > 0 && d->dg > 0 && d->hg > 0 && d->wg > 0,
+                   "ctsi_wgrad: bad spatial sizes");
+    CTSI_CHECK_ARG(d->cr > 0 && d->cg > 0 && (d->cr % 8) == 0 && (d->cg % 8) == 0 && (d->cr_stride % 8) == 0 &&
+                       (d->cg_stride % 8) == 0 && d->cr <= d->cr_stride && d->cg <= d->cg_stride,
+                   "ctsi_wgrad: channel counts must be multiples of 8 (cr=%d/%d cg=%d/%d)", d->cr, d->cr_stride, d->cg,
+                   d->cg_stride);
+    g->V = (long long)d->n * d->dr * d->hr * d->wr;
+    const long long rb = g->V * d->cr_stride * 2, gb = (long long)d->n * d->dg * d->hg * d->wg * d->cg_stride * 2;
+    CTSI_CHECK_ARG(g->V < (1ll << 31) - 64 && rb < 0xffffff00ll && gb < 0xffffff00ll,
+                   "ctsi_wgrad: tensor larger than one 4 GiB buffer descriptor");
+    g->T = d->kd * d->kh * d->kw;
+    g->tiles_r = (d->cr + wgk::BR - 1) / wgk::BR;
+    g->tiles_g = (d->cg + wgk::BG - 1) / wgk::BG;
+    g->ksteps = (int)((g->V + wgk::BK - 1) / wgk::BK);
+    const int combos = g->T * g->tiles_r * g->tiles_g;
+    int S = (2048 + combos - 1) / combos;          // aim at >= 2048 blocks (256 CUs x 2 x 4)
+    const int smax = (g->ksteps + 15) / 16;        // at least 16 K-steps (512 voxels) per slice
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    g->kps = (g->ksteps + S - 1) / S;
+    g->S = (g->ksteps + g->kps - 1) / g->kps;
+    return CTSI_OK;
+}
+
+extern "C" size_t ctsi_wgrad_workspace_bytes(const ctsi_wgrad_desc* d) {
+    WgradGeom g;
+    if (wg_geometry(d, &g) != CTSI_OK) return 0;
+    return (size_t)g.S * g.T * (size_t)(g.tiles_r * wgk::BR) * (g.tiles_g * wgk::BG) * sizeof(float);
+}
+
+extern "C" double ctsi_wgrad_flops(const ctsi_wgrad_desc* d) {
+    WgradGeom g;
+    if (wg_geometry(d, &g) != CTSI_OK) return 0.0;
+    return 2.0 * (double)g.V * d->cr * d->cg * g.T;
+}
+
+extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* gt, void* workspace, float* dw,
+                          long long stride_r, long long stride_g, long long stride_t, float scale, void* stream) {
+    WgradGeom g;
+    int rc = wg_geometry(d, &g);
+    if (rc != CTSI_OK) return rc;
+    CTSI_CHECK_ARG(r && gt && workspace && dw, "ctsi_wgrad: null pointer");
+    WgradParams p;
+    p.R = (const bf16_t*)r;
+    p.G = (const bf16_t*)gt;
+    p.part = (float*)workspace;
+    p.r_bytes = (unsigned)(g.V * d->cr_stride * 2);
+    p.g_bytes = (unsigned)((long long)d->n * d->dg * d->hg * d->wg * d->cg_stride * 2);
+    p.CR = d->cr; p.CRs = d->cr_stride; p.CG = d->cg; p.CGs = d->cg_stride;
+    p.N = d->n; p.Dr = d->dr; p.Hr = d->hr; p.Wr = d->wr; p.Dg = d->dg; p.Hg = d->hg; p.Wg = d->wg;
+    p.KH = d->kh; p.KW = d->kw; p.sh = d->sh; p.sw = d->sw; p.pd = d->pd; p.ph = d->ph; p.pw = d->pw;
+    p.T = g.T; p.tiles_r = g.tiles_r; p.tiles_g = g.tiles_g; p.S = g.S; p.ksteps = g.ksteps; p.kps = g.kps;
+    p.V = (int)g.V;
+    wg_magic((unsigned)d->wr, &p.mW, &p.shW);
+    wg_magic((unsigned)d->hr, &p.mH, &p.shH);
+    wg_magic((unsigned)d->dr, &p.mD, &p.shD);
+    const long long blocks = (long long)g.T * g.tiles_r * g.tiles_g * g.S;
+    CTSI_CHECK_ARG(blocks < (1ll << 31), "ctsi_wgrad: grid too large");
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(wgk::NTH), wgk::LDS_BYTES, (hipStream_t)stream, p);
+    CTSI_LAUNCH_CHECK();
+    const long long total = (long long)d->cr * d->cg;
+    long long rb = (total + 255) / 256;
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, dw, g.S, g.T, g.tiles_r * wgk::BR, g.tiles_g * wgk::BG, d->cr, d->cg,
+                       stride_r, stride_g, stride_t, scale);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}

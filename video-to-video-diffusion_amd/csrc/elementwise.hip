@@ -220,6 +220,35 @@ extern "C" int ctsi_time_embed_fwd(const int* t_rows, int rows, int dim, int tim
     return CTSI_OK;
 }
 
+// Training variant: scratch keeps the PRE-activation of the first Linear (the backward needs SiLU' of it);
+// the SiLU moves into the second Linear's input.  Same values as ctsi_time_embed_fwd.
+extern "C" int ctsi_time_embed_train_fwd(const int* t_rows, int rows, int dim, int time_dim, const float* w1,
+                                         const float* b1, const float* w2, const float* b2, const float* w_all,
+                                         const float* b_all, int total_out, float* scratch, float* tbias_out,
+                                         void* stream) {
+    CTSI_CHECK_ARG(t_rows && w1 && b1 && w2 && b2 && scratch && w_all && b_all && tbias_out,
+                   "ctsi_time_embed_train_fwd: null argument");
+    CTSI_CHECK_ARG(rows > 0 && dim >= 4 && dim % 2 == 0 && dim <= 2048 && time_dim > 0 && time_dim <= 2048,
+                   "ctsi_time_embed_train_fwd: unsupported sizes dim=%d time_dim=%d", dim, time_dim);
+    hipStream_t st = (hipStream_t)stream;
+    float* sincos = scratch;                           // rows*dim
+    float* lin1 = scratch + (long long)rows * dim;     // rows*time_dim, pre-activation
+    float* temb = lin1 + (long long)rows * time_dim;   // rows*time_dim
+    int blocks = (rows * (dim / 2) + 255) / 256;
+    hipLaunchKernelGGL(time_sincos_kernel, dim3(blocks), dim3(256), 0, st, t_rows, rows, dim, sincos);
+    CTSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(time_linear_kernel, dim3((time_dim + 3) / 4), dim3(256), 0, st, sincos, rows, dim, w1, b1,
+                       time_dim, lin1, 0, 0);
+    CTSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(time_linear_kernel, dim3((time_dim + 3) / 4), dim3(256), 0, st, lin1, rows, time_dim, w2, b2,
+                       time_dim, temb, 1, 0);
+    CTSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(time_linear_kernel, dim3((total_out + 3) / 4), dim3(256), 0, st, temb, rows, time_dim, w_all,
+                       b_all, total_out, tbias_out, 1, 0);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
 // ---- sampler updates ---------------------------------------------------------------------------------------------------
 // coef row layout (8 floats), built on the host with fp32 torch ops exactly as the reference does:
 //  DDIM: [0]=sqrt(1-a_t+1e-8) [1]=sqrt(a_t+1e-8)+1e-8 [2]=sqrt(a_prev+1e-8) [3]=sqrt(1-a_prev+1e-8) [4]=sigma_t

@@ -1,0 +1,582 @@
+// Training-path kernels other than the convolutions (all HBM- or latency-bound):
+//   q_sample + Min-SNR-5 weighted MSE loss        models/diffusion.py:81-106, 108-203
+//   GroupNorm (+SiLU, +time bias, +residual) backward   (what autograd derives for models/unet3d.py:51-133)
+//   data-gradient weight re-layout, channel sums (bias gradients), small fp32 Linear backward (time embedding)
+// Activations and their gradients are bf16 NDHWC with 16-byte (8-channel) accesses; statistics and parameter
+// gradients are fp32 / fp64.  Reductions are two-stage with a fixed order (deterministic, no float atomics).
+#include "ctsi_internal.h"
+#include <math.h>
+
+#define GNB_TILE_ROWS 512
+
+__device__ __forceinline__ void t_unpack8(const uint4 v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 t_pack8(const float* f) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+// d/dz [z * sigmoid(z)]
+__device__ __forceinline__ float silu_grad_f(float z) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+// ==== GroupNorm backward ============================================================================================
+// forward (ctsi_gn_apply):  h = gn(x);  a = silu_pre ? silu(h) : h;  b = a + tbias;  c = b + residual;
+//                           y = silu_post ? silu(c) : c
+// backward: gc = dy * (silu_post ? silu'(c) : 1)   (= grad of residual; its per-sample channel sum = grad of tbias)
+//           g  = gc * (silu_pre ? silu'(h) : 1)    (= grad of h)
+//           dx = rstd * (gamma*g - mean_grp(gamma*g) - xhat * mean_grp(gamma*g*xhat))
+//           dgamma = sum g*xhat, dbeta = sum g.
+// Pass 1 (this kernel): writes g (bf16) and per-tile column sums [n][tiles][3][c] = (sum g, sum g*xhat, sum gc).
+// grid (tiles, n), block 256.  dy may be a depth-broadcast tensor (n, 1, h, w, c): dy_mod = h*w, else 0.
+__global__ void __launch_bounds__(256)
+gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, long long dy_mod,
+                     const double* __restrict__ sums, const float* __restrict__ gamma,
+                     const float* __restrict__ beta, int c, long long vox, int groups, float eps, int silu_pre,
+                     const bf16_t* __restrict__ residual, int silu_post, bf16_t* __restrict__ g_out,
+                     float* __restrict__ colsum3, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_rs = reinterpret_cast<float*>(smem_raw);   // rstd
+    float* s_mr = s_rs + c;                              // -mean*rstd
+    float* s_ga = s_mr + c;
+    float* s_be = s_ga + c;
+    float* s_red = s_be + c;                             // [rows_par][3][c]
+    const int nb = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int cpg = c / groups;
+    const double cnt = (double)cpg * (double)vox;
+    for (int ch = tid; ch < c; ch += 256) {
+        const int g = ch / cpg;
+        const double m = sums[((long long)nb * groups + g) * 2 + 0] / cnt;
+        double var = sums[((long long)nb * groups + g) * 2 + 1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        s_rs[ch] = rstd;
+        s_mr[ch] = -(float)m * rstd;
+        s_ga[ch] = gamma[ch];
+        s_be[ch] = beta[ch];
+    }
+    __syncthreads();
+    const int cpr = c >> 3;
+    const int rows_par = 256 / cpr;
+    const int q = tid % cpr, rl = tid / cpr;
+    const long long v0 = (long long)tile * GNB_TILE_ROWS;
+    long long v1 = v0 + GNB_TILE_ROWS;
+    if (v1 > vox) v1 = vox;
+    float a0[8], a1[8], a2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a0[k] = a1[k] = a2[k] = 0.0f;
+    if (rl < rows_par) {
+        const bf16_t* xb = x + (long long)nb * vox * c + q * 8;
+        const bf16_t* rb = residual ? residual + (long long)nb * vox * c + q * 8 : nullptr;
+        bf16_t* gb = g_out + (long long)nb * vox * c + q * 8;
+        const bf16_t* db = dy + (long long)nb * (dy_mod ? dy_mod : vox) * c + q * 8;
+        float rs[8], mr[8], ga[8], be[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            rs[k] = s_rs[q * 8 + k]; mr[k] = s_mr[q * 8 + k]; ga[k] = s_ga[q * 8 + k]; be[k] = s_be[q * 8 + k];
+        }
+        for (long long v = v0 + rl; v < v1; v += rows_par) {
+            float xf[8], df[8], rf[8], gf[8];
+            t_unpack8(*reinterpret_cast<const uint4*>(xb + v * c), xf);
+            const long long dv = dy_mod ? (v % dy_mod) : v;
+            t_unpack8(*reinterpret_cast<const uint4*>(db + dv * c), df);
+            if (rb) t_unpack8(*reinterpret_cast<const uint4*>(rb + v * c), rf);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xh = xf[k] * rs[k] + mr[k];
+                const float h = xh * ga[k] + be[k];
+                float gc = df[k];
+                if (silu_post) {
+                    float cc = silu_pre ? silu_f(h) : h;
+                    if (rb) cc += rf[k];
+                    gc *= silu_grad_f(cc);
+                }
+                float g = gc;
+                if (silu_pre) g *= silu_grad_f(h);
+                gf[k] = g;
+                a0[k] += g;
+                a1[k] += g * xh;
+                a2[k] += gc;
+            }
+            *reinterpret_cast<uint4*>(gb + v * c) = t_pack8(gf);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s_red[(rl * 3 + 0) * c + q * 8 + k] = a0[k];
+            s_red[(rl * 3 + 1) * c + q * 8 + k] = a1[k];
+            s_red[(rl * 3 + 2) * c + q * 8 + k] = a2[k];
+        }
+    }
+    __syncthreads();
+    float* out = colsum3 + ((long long)nb * tiles + tile) * 3 * c;
+    for (int e = tid; e < 3 * c; e += 256) {
+        float t = 0.0f;
+        for (int r = 0; r < rows_par; ++r) t += s_red[r * 3 * c + e];
+        out[e] = t;
+    }
+}
+
+// Pass 2a: grid n, block 256.  Sums the tiles, forms the group terms, writes per-sample partial parameter grads.
+//   s12[n][groups][2] = (sum_grp gamma*g, sum_grp gamma*g*xhat) / m ;  pgrad[n][3][c] = (sum g*xhat, sum g, sum gc)
+__global__ void __launch_bounds__(256)
+gn_bwd_finalize_kernel(const float* __restrict__ colsum3, const float* __restrict__ gamma, int c, long long vox,
+                       int groups, int tiles, float* __restrict__ s12, float* __restrict__ pgrad) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_a = reinterpret_cast<float*>(smem_raw);  // gamma * sum g
+    float* s_b = s_a + c;                              // gamma * sum g*xhat
+    const int nb = blockIdx.x, tid = threadIdx.x;
+    const float* base = colsum3 + (long long)nb * tiles * 3 * c;
+    for (int ch = tid; ch < c; ch += 256) {
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+        for (int t = 0; t < tiles; ++t) {
+            t0 += base[((long long)t * 3 + 0) * c + ch];
+            t1 += base[((long long)t * 3 + 1) * c + ch];
+            t2 += base[((long long)t * 3 + 2) * c + ch];
+        }
+        s_a[ch] = gamma[ch] * t0;
+        s_b[ch] = gamma[ch] * t1;
+        pgrad[((long long)nb * 3 + 0) * c + ch] = t1;
+        pgrad[((long long)nb * 3 + 1) * c + ch] = t0;
+        pgrad[((long long)nb * 3 + 2) * c + ch] = t2;
+    }
+    __syncthreads();
+    const int cpg = c / groups;
+    const float inv_m = (float)(1.0 / ((double)cpg * (double)vox));
+    for (int g = tid; g < groups; g += 256) {
+        float sa = 0.0f, sb = 0.0f;
+        for (int k = 0; k < cpg; ++k) {
+            sa += s_a[g * cpg + k];
+            sb += s_b[g * cpg + k];
+        }
+        s12[((long long)nb * groups + g) * 2 + 0] = sa * inv_m;
+        s12[((long long)nb * groups + g) * 2 + 1] = sb * inv_m;
+    }
+}
+
+// Pass 2b: dgamma[c] = sum_n pgrad[n][0][c], dbeta[c] = sum_n pgrad[n][1][c]; dtb[n][c] = pgrad[n][2][c] (optional,
+// row stride dtb_stride)
+__global__ void __launch_bounds__(256)
+gn_bwd_param_kernel(const float* __restrict__ pgrad, int n, int c, float* __restrict__ dgamma,
+                    float* __restrict__ dbeta, float* __restrict__ dtb, long long dtb_stride) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    float a = 0.0f, b = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        a += pgrad[((long long)i * 3 + 0) * c + ch];
+        b += pgrad[((long long)i * 3 + 1) * c + ch];
+        if (dtb) dtb[(long long)i * dtb_stride + ch] = pgrad[((long long)i * 3 + 2) * c + ch];
+    }
+    dgamma[ch] = a;
+    dbeta[ch] = b;
+}
+
+// Pass 3: dx = rstd*(gamma*g - S1/m - xhat*S2/m) (+ add).  grid (blocks, n), block 256.
+__global__ void __launch_bounds__(256)
+gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, const double* __restrict__ sums,
+                    const float* __restrict__ gamma, const float* __restrict__ s12,
+                    const bf16_t* __restrict__ add, bf16_t* __restrict__ dx, int c, long long vox, int groups,
+                    float eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_rs = reinterpret_cast<float*>(smem_raw);
+    float* s_mr = s_rs + c;
+    float* s_ag = s_mr + c;   // rstd*gamma
+    float* s_b1 = s_ag + c;   // rstd*S1/m
+    float* s_b2 = s_b1 + c;   // rstd*S2/m
+    const int nb = blockIdx.y, tid = threadIdx.x;
+    const int cpg = c / groups;
+    const double cnt = (double)cpg * (double)vox;
+    for (int ch = tid; ch < c; ch += 256) {
+        const int gi = ch / cpg;
+        const double m = sums[((long long)nb * groups + gi) * 2 + 0] / cnt;
+        double var = sums[((long long)nb * groups + gi) * 2 + 1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        s_rs[ch] = rstd;
+        s_mr[ch] = -(float)m * rstd;
+        s_ag[ch] = rstd * gamma[ch];
+        s_b1[ch] = rstd * s12[((long long)nb * groups + gi) * 2 + 0];
+        s_b2[ch] = rstd * s12[((long long)nb * groups + gi) * 2 + 1];
+    }
+    __syncthreads();
+    const int cpr = c >> 3;
+    const long long total = vox * cpr;
+    const bf16_t* gb = g + (long long)nb * vox * c;
+    const bf16_t* xb = x + (long long)nb * vox * c;
+    const bf16_t* ab = add ? add + (long long)nb * vox * c : nullptr;
+    bf16_t* ob = dx + (long long)nb * vox * c;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long e = (long long)blockIdx.x * 256 + tid; e < total; e += stride) {
+        const int q = (int)(e % cpr);
+        float gf[8], xf[8], af[8], of[8];
+        t_unpack8(*reinterpret_cast<const uint4*>(gb + e * 8), gf);
+        t_unpack8(*reinterpret_cast<const uint4*>(xb + e * 8), xf);
+        if (ab) t_unpack8(*reinterpret_cast<const uint4*>(ab + e * 8), af);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ch = q * 8 + k;
+            const float xh = xf[k] * s_rs[ch] + s_mr[ch];
+            float v = s_ag[ch] * gf[k] - s_b1[ch] - xh * s_b2[ch];
+            if (ab) v += af[k];
+            of[k] = v;
+        }
+        *reinterpret_cast<uint4*>(ob + e * 8) = t_pack8(of);
+    }
+}
+
+extern "C" int ctsi_gn_bwd_tiles(int d, int h, int w) {
+    const long long vox = (long long)d * h * w;
+    return (int)((vox + GNB_TILE_ROWS - 1) / GNB_TILE_ROWS);
+}
+
+extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const double* sums, const float* gamma,
+                           const float* beta, int n, int c, int d, int h, int w, int groups, float eps, int silu_pre,
+                           const void* residual, int silu_post, const void* add, void* g_buf, void* dx,
+                           float* workspace, float* dgamma, float* dbeta, float* dtbias, long long dtbias_stride,
+                           void* stream) {
+    CTSI_CHECK_ARG(x && dy && sums && gamma && beta && g_buf && dx && workspace && dgamma && dbeta,
+                   "ctsi_gn_bwd: null argument");
+    CTSI_CHECK_ARG(c % 8 == 0 && c <= 2048 && groups > 0 && c % groups == 0, "ctsi_gn_bwd: bad c=%d groups=%d", c,
+                   groups);
+    const long long vox = (long long)d * h * w;
+    const int tiles = ctsi_gn_bwd_tiles(d, h, w);
+    hipStream_t st = (hipStream_t)stream;
+    // workspace: colsum3 [n][tiles][3][c] | s12 [n][groups][2] | pgrad [n][3][c]
+    float* colsum3 = workspace;
+    float* s12 = colsum3 + (long long)n * tiles * 3 * c;
+    float* pgrad = s12 + (long long)n * groups * 2;
+    const int cpr = c >> 3;
+    const int rows_par = 256 / cpr;
+    CTSI_CHECK_ARG(rows_par >= 1, "ctsi_gn_bwd: c=%d too wide", c);
+    const size_t lds1 = (size_t)(4 * c + rows_par * 3 * c) * sizeof(float);
+    CTSI_CHECK_ARG(lds1 <= 160 * 1024, "ctsi_gn_bwd: LDS budget exceeded for c=%d", c);
+    if (lds1 > 64 * 1024)
+        CTSI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_bwd_reduce_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(tiles, n), dim3(256), lds1, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       dy_bcast_d ? (long long)h * w : 0ll, sums, gamma, beta, c, vox, groups, eps, silu_pre,
+                       (const bf16_t*)residual, silu_post, (bf16_t*)g_buf, colsum3, tiles);
+    CTSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n), dim3(256), 2 * c * sizeof(float), st, colsum3, gamma, c, vox,
+                       groups, tiles, s12, pgrad);
+    CTSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, st, pgrad, n, c, dgamma, dbeta, dtbias,
+                       dtbias_stride);
+    CTSI_LAUNCH_CHECK();
+    const long long total = vox * cpr;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)blocks, n), dim3(256), 5 * c * sizeof(float), st,
+                       (const bf16_t*)g_buf, (const bf16_t*)x, sums, gamma, s12, (const bf16_t*)add, (bf16_t*)dx, c, vox,
+                       groups, eps);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+extern "C" size_t ctsi_gn_bwd_workspace_floats(int n, int c, int d, int h, int w, int groups) {
+    const long long tiles = ctsi_gn_bwd_tiles(d, h, w);
+    return (size_t)((long long)n * tiles * 3 * c + (long long)n * groups * 2 + (long long)n * 3 * c);
+}
+
+// ==== channel sums (bias gradients) ==================================================================================
+// partial[b][c] over row blocks, then out[c] = scale * sum_b partial[b][c]
+__global__ void __launch_bounds__(256)
+channel_sum_partial_kernel(const bf16_t* __restrict__ x, long long rows, int c, int c_stride,
+                           float* __restrict__ partial, long long rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_red = reinterpret_cast<float*>(smem_raw);  // [rows_par][c]
+    const int cpr = c >> 3;
+    const int rows_par = 256 / cpr;
+    const int tid = threadIdx.x, q = tid % cpr, rl = tid / cpr;
+    const long long v0 = (long long)blockIdx.x * rows_per_block;
+    long long v1 = v0 + rows_per_block;
+    if (v1 > rows) v1 = rows;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.0f;
+    if (rl < rows_par) {
+        for (long long v = v0 + rl; v < v1; v += rows_par) {
+            float f[8];
+            t_unpack8(*reinterpret_cast<const uint4*>(x + v * c_stride + q * 8), f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += f[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_red[rl * c + q * 8 + k] = a[k];
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 256) {
+        float t = 0.0f;
+        for (int r = 0; r < rows_par; ++r) t += s_red[r * c + ch];
+        partial[(long long)blockIdx.x * c + ch] = t;
+    }
+}
+__global__ void __launch_bounds__(256)
+channel_sum_final_kernel(const float* __restrict__ partial, int blocks, int c, float* __restrict__ out, float scale) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    float t = 0.0f;
+    for (int b = 0; b < blocks; ++b) t += partial[(long long)b * c + ch];
+    out[ch] = t * scale;
+}
+#define CHSUM_ROWS 1024
+extern "C" size_t ctsi_channel_sum_workspace_floats(long long rows, int c) {
+    return (size_t)(((rows + CHSUM_ROWS - 1) / CHSUM_ROWS) * c);
+}
+extern "C" int ctsi_channel_sum(const void* x, long long rows, int c, int c_stride, float* workspace, float* out,
+                                float scale, void* stream) {
+    CTSI_CHECK_ARG(x && workspace && out && rows > 0 && c > 0 && c % 8 == 0 && c <= 2048 && c_stride % 8 == 0 &&
+                       c_stride >= c, "ctsi_channel_sum: bad arguments (c=%d stride=%d)", c, c_stride);
+    const long long blocks = (rows + CHSUM_ROWS - 1) / CHSUM_ROWS;
+    const int rows_par = 256 / (c >> 3);
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3((unsigned)blocks), dim3(256), (size_t)rows_par * c * sizeof(float),
+                       (hipStream_t)stream, (const bf16_t*)x, rows, c, c_stride, workspace, (long long)CHSUM_ROWS);
+    CTSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
+                       (int)blocks, c, out, scale);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// ==== small elementwise helpers ======================================================================================
+__global__ void __launch_bounds__(256) add_bf16_kernel(bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long long chunks) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < chunks; e += (long long)gridDim.x * 256) {
+        float fa[8], fb[8];
+        t_unpack8(*reinterpret_cast<const uint4*>(a + e * 8), fa);
+        t_unpack8(*reinterpret_cast<const uint4*>(b + e * 8), fb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fa[k] += fb[k];
+        *reinterpret_cast<uint4*>(a + e * 8) = t_pack8(fa);
+    }
+}
+extern "C" int ctsi_add_bf16(void* a, const void* b, long long count, void* stream) {
+    CTSI_CHECK_ARG(a && b && count >= 0 && count % 8 == 0, "ctsi_add_bf16: count must be a multiple of 8");
+    if (count == 0) return CTSI_OK;
+    long long blocks = (count / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)a,
+                       (const bf16_t*)b, count / 8);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// fp32 [rows][c] -> bf16 [rows][c]
+__global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long count) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256)
+        dst[e] = f32_to_bf16(src[e]);
+}
+extern "C" int ctsi_f32_to_bf16(const float* src, void* dst, long long count, void* stream) {
+    CTSI_CHECK_ARG(src && dst && count >= 0, "ctsi_f32_to_bf16: bad arguments");
+    if (count == 0) return CTSI_OK;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, count);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// out (cout' = ci_cnt, cin' = cout, T):  out[(ci' * cout + co) * T + (T-1-t)] = w[(co * cin + ci_off + ci') * T + t]
+__global__ void __launch_bounds__(256)
+weight_dgrad_layout_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int taps, int ci_off,
+                           int ci_cnt, long long total) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int t = (int)(e % taps);
+        const long long r = e / taps;
+        const int co = (int)(r % cout);
+        const int ci = (int)(r / cout);
+        out[e] = w[((long long)co * cin + ci_off + ci) * taps + (taps - 1 - t)];
+    }
+}
+extern "C" int ctsi_weight_dgrad_layout(const float* w, float* out, int cout, int cin, int taps, int ci_off, int ci_cnt,
+                                        void* stream) {
+    CTSI_CHECK_ARG(w && out && cout > 0 && cin > 0 && taps > 0 && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= cin,
+                   "ctsi_weight_dgrad_layout: bad arguments");
+    const long long total = (long long)ci_cnt * cout * taps;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(weight_dgrad_layout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, cout,
+                       cin, taps, ci_off, ci_cnt, total);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// ==== q_sample and the loss ============================================================================================
+// z_t = sqrt_ac[t_b] * z0 + sqrt_1mac[t_b] * noise     (fp32 NCDHW in) -> bf16 NDHWC channels [c_off, c_off + c)
+__global__ void __launch_bounds__(256)
+q_sample_kernel(const float* __restrict__ z0, const float* __restrict__ noise, const float* __restrict__ sqrt_ac,
+                const float* __restrict__ sqrt_1mac, const int* __restrict__ t, bf16_t* __restrict__ dst, int c,
+                long long vox, int c_total, int c_off, long long total /* n*vox */) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long nb = e / vox, v = e - nb * vox;
+        const int tt = t[nb];
+        const float a = sqrt_ac[tt], s = sqrt_1mac[tt];
+        for (int ch = 0; ch < c; ++ch) {
+            const long long i = (nb * c + ch) * vox + v;
+            dst[e * c_total + c_off + ch] = f32_to_bf16(a * z0[i] + s * noise[i]);
+        }
+    }
+}
+extern "C" int ctsi_q_sample(const float* z0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac,
+                             const int* t, void* dst, int n, int c, int d, int h, int w, int c_total, int c_off,
+                             void* stream) {
+    CTSI_CHECK_ARG(z0 && noise && sqrt_ac && sqrt_1mac && t && dst && n > 0 && c > 0 && c_off >= 0 && c_off + c <= c_total,
+                   "ctsi_q_sample: bad arguments");
+    const long long vox = (long long)d * h * w, total = vox * n;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z0, noise, sqrt_ac,
+                       sqrt_1mac, t, (bf16_t*)dst, c, vox, c_total, c_off, total);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// loss = sum_b norm[b] * sum_e mask * (pred - noise)^2.   pred: fp32 NDHWC (n, vox, c); noise: fp32 NCDHW;
+// mask: fp32 (n, c, d) or NULL.  Also d_pred (bf16 NDHWC, c_stride channels per voxel) = 2*norm[b]*mask*(pred-noise)*gscale.
+// Stage 1: per-block partial sums in double; stage 2 (one block): loss_out[0] = total, loss_out[1+b] = per-sample
+// unnormalised sums.
+#define LOSS_BLOCKS_PER_SAMPLE 64
+__global__ void __launch_bounds__(256)
+mse_loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ noise, const float* __restrict__ mask,
+                        int c, long long vox, long long hw, int d, double* __restrict__ partial) {
+    __shared__ double s_red[256];
+    const int nb = blockIdx.y;
+    const long long total = vox * c;
+    double acc = 0.0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int ch = (int)(e % c);
+        const long long v = e / c;
+        float df = pred[(long long)nb * total + e] - noise[((long long)nb * c + ch) * vox + v];
+        float m = 1.0f;
+        if (mask) m = mask[((long long)nb * c + ch) * d + (v / hw)];
+        acc += (double)(m * df * df);
+    }
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(long long)nb * gridDim.x + blockIdx.x] = s_red[0];
+}
+__global__ void mse_loss_final_kernel(const double* __restrict__ partial, const float* __restrict__ norm, int n, int bps,
+                                      float* __restrict__ loss_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double total = 0.0;
+    for (int b = 0; b < n; ++b) {
+        double s = 0.0;
+        for (int k = 0; k < bps; ++k) s += partial[(long long)b * bps + k];
+        loss_out[1 + b] = (float)s;
+        total += (double)norm[b] * s;
+    }
+    loss_out[0] = (float)total;
+}
+extern "C" int ctsi_mse_loss_fwd(const float* pred, const float* noise, const float* mask, const float* norm, int n,
+                                 int c, int d, int h, int w, double* workspace, float* loss_out, void* stream) {
+    CTSI_CHECK_ARG(pred && noise && norm && workspace && loss_out && n > 0 && c > 0, "ctsi_mse_loss_fwd: bad arguments");
+    const long long hw = (long long)h * w, vox = hw * d;
+    hipLaunchKernelGGL(mse_loss_partial_kernel, dim3(LOSS_BLOCKS_PER_SAMPLE, n), dim3(256), 0, (hipStream_t)stream, pred,
+                       noise, mask, c, vox, hw, d, workspace);
+    CTSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mse_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, norm, n,
+                       LOSS_BLOCKS_PER_SAMPLE, loss_out);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+extern "C" size_t ctsi_mse_loss_workspace_doubles(int n) { return (size_t)n * LOSS_BLOCKS_PER_SAMPLE; }
+
+__global__ void __launch_bounds__(256)
+mse_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ noise, const float* __restrict__ mask,
+                    const float* __restrict__ norm, const float* __restrict__ gscale, int c, long long vox, long long hw,
+                    int d, bf16_t* __restrict__ dpred, int c_stride, long long total /* n*vox*c_stride */) {
+    const float gs = gscale ? gscale[0] : 1.0f;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int ch = (int)(e % c_stride);
+        const long long nv = e / c_stride;
+        const long long nb = nv / vox, v = nv - nb * vox;
+        float out = 0.0f;
+        if (ch < c) {
+            const float df = pred[nv * c + ch] - noise[(nb * c + ch) * vox + v];
+            float m = 1.0f;
+            if (mask) m = mask[(nb * c + ch) * d + (v / hw)];
+            out = 2.0f * norm[nb] * m * df * gs;
+        }
+        dpred[e] = f32_to_bf16(out);
+    }
+}
+extern "C" int ctsi_mse_loss_bwd(const float* pred, const float* noise, const float* mask, const float* norm,
+                                 const float* gscale, int n, int c, int d, int h, int w, void* dpred, int c_stride,
+                                 void* stream) {
+    CTSI_CHECK_ARG(pred && noise && norm && dpred && n > 0 && c > 0 && c_stride >= c, "ctsi_mse_loss_bwd: bad arguments");
+    const long long hw = (long long)h * w, vox = hw * d, total = vox * n * c_stride;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mse_loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, noise, mask,
+                       norm, gscale, c, vox, hw, d, (bf16_t*)dpred, c_stride, total);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// ==== fp32 Linear backward for the time embedding (rows <= 64) ========================================================
+// y = act_in(x) W^T + b with act_in = SiLU when silu_in (x is then the pre-activation):
+//   dw[o][i] = sum_r dy[r][o] * a[r][i];  db[o] = sum_r dy[r][o];  dx[r][i] = (sum_o dy[r][o] w[o][i]) * act_in'(x[r][i])
+__global__ void __launch_bounds__(256)
+linear_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy, int rows, int in_dim, int out_dim,
+                    int silu_in, float* __restrict__ dw, float* __restrict__ db) {
+    const long long total = (long long)out_dim * in_dim;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int o = (int)(e / in_dim), i = (int)(e - (long long)o * in_dim);
+        float s = 0.0f;
+        for (int r = 0; r < rows; ++r) {
+            float a = x[(long long)r * in_dim + i];
+            if (silu_in) a = a / (1.0f + expf(-a));
+            s += dy[(long long)r * out_dim + o] * a;
+        }
+        dw[e] = s;
+        if (i == 0 && db) {
+            float b = 0.0f;
+            for (int r = 0; r < rows; ++r) b += dy[(long long)r * out_dim + o];
+            db[o] = b;
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+linear_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy, int rows,
+                    int in_dim, int out_dim, int silu_in, int accumulate, float* __restrict__ dx) {
+    const long long total = (long long)rows * in_dim;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int r = (int)(e / in_dim), i = (int)(e - (long long)r * in_dim);
+        float s = 0.0f;
+        for (int o = 0; o < out_dim; ++o) s += dy[(long long)r * out_dim + o] * w[(long long)o * in_dim + i];
+        if (silu_in) {
+            const float z = x[e];
+            const float sg = 1.0f / (1.0f + expf(-z));
+            s *= sg * (1.0f + z * (1.0f - sg));
+        }
+        dx[e] = accumulate ? dx[e] + s : s;
+    }
+}
+extern "C" int ctsi_linear_bwd(const float* x, const float* w, const float* dy, int rows, int in_dim, int out_dim,
+                               int silu_in, float* dw, float* db, float* dx, void* stream) {
+    CTSI_CHECK_ARG(x && w && dy && rows > 0 && rows <= 64 && in_dim > 0 && out_dim > 0, "ctsi_linear_bwd: bad arguments");
+    if (dw) {
+        const long long total = (long long)out_dim * in_dim;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, rows,
+                           in_dim, out_dim, silu_in, dw, db);
+        CTSI_LAUNCH_CHECK();
+    }
+    if (dx) {
+        const long long total = (long long)rows * in_dim;
+        hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                           w, dy, rows, in_dim, out_dim, silu_in, 0, dx);
+        CTSI_LAUNCH_CHECK();
+    }
+    return CTSI_OK;
+}

@@ -47,6 +47,19 @@ class ConvOut(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("kd", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+        ("sh", C.c_int), ("sw", C.c_int),
+        ("pd", C.c_int), ("ph", C.c_int), ("pw", C.c_int),
+        ("n", C.c_int),
+        ("dr", C.c_int), ("hr", C.c_int), ("wr", C.c_int),
+        ("dg", C.c_int), ("hg", C.c_int), ("wg", C.c_int),
+        ("cr", C.c_int), ("cr_stride", C.c_int),
+        ("cg", C.c_int), ("cg_stride", C.c_int),
+    ]
+
+
 _vp, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
 _ip = C.POINTER(C.c_int)
 
@@ -87,6 +100,24 @@ SIGNATURES = {
     "ctsi_ddpm_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_step_advance": (_i, [_vp, _vp], True),
     "ctsi_nan_to_num_f32": (_i, [_vp, _ll, _vp], True),
+    "ctsi_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)], False),
+    "ctsi_wgrad_flops": (C.c_double, [C.POINTER(WgradDesc)], False),
+    "ctsi_wgrad": (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, _ll, _ll, _ll, _f, _vp], True),
+    "ctsi_weight_dgrad_layout": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp], True),
+    "ctsi_gn_bwd_tiles": (_i, [_i, _i, _i], False),
+    "ctsi_gn_bwd_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i], False),
+    "ctsi_gn_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp, _vp, _vp,
+                         _vp, _vp, _vp, _ll, _vp], True),
+    "ctsi_channel_sum_workspace_floats": (_sz, [_ll, _i], False),
+    "ctsi_channel_sum": (_i, [_vp, _ll, _i, _i, _vp, _vp, _f, _vp], True),
+    "ctsi_add_bf16": (_i, [_vp, _vp, _ll, _vp], True),
+    "ctsi_f32_to_bf16": (_i, [_vp, _vp, _ll, _vp], True),
+    "ctsi_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], True),
+    "ctsi_mse_loss_workspace_doubles": (_sz, [_i], False),
+    "ctsi_mse_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], True),
+    "ctsi_mse_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp], True),
+    "ctsi_time_embed_train_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp], True),
+    "ctsi_linear_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp], True),
     "ctsi_blend_accumulate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_blend_normalize": (_i, [_vp, _vp, _ll, _vp], True),
     "ctsi_memset_async": (_i, [_vp, _i, _sz, _vp], True),

@@ -298,6 +298,50 @@ def generate(sd: SD, cfg: dict, v_in, sampler: str, n_steps: int, target_depth: 
     return _guard(vae_decode(sd, _guard(z0), sf, "vae."))
 
 
+def q_sample(bufs: SD, z0, t, noise):
+    """ref models/diffusion.py:81-106"""
+    a = bufs["sqrt_alphas_cumprod"][t].float().view(-1, 1, 1, 1, 1)
+    s = bufs["sqrt_one_minus_alphas_cumprod"][t].float().view(-1, 1, 1, 1, 1)
+    return a * z0 + s * noise
+
+
+def training_loss(sd: SD, cfg: dict, z0, cond, t, noise, mask=None, prefix: str = "unet."):
+    """ref models/diffusion.py:108-203 (MSE part; t and noise are given instead of drawn).  Differentiable with
+    respect to every tensor of `sd` that requires grad."""
+    bufs = {k[len("diffusion."):]: v for k, v in sd.items() if k.startswith("diffusion.")}
+    B = z0.shape[0]
+    z_t = q_sample(bufs, z0, t, noise)
+    pred = unet_forward(sd, cfg, z_t, t, cond, prefix)
+    ac = bufs["alphas_cumprod"][t]
+    snr = ac / (1 - ac + 1e-8)
+    w = torch.clamp(snr, max=5.0) / (snr + 1e-8)
+    if mask is None:
+        per = F.mse_loss(pred, noise, reduction="none").reshape(B, -1).mean(dim=1)
+        return (per * w).mean()
+    me = mask.unsqueeze(-1).unsqueeze(-1).expand_as(pred)
+    masked = ((pred - noise) ** 2) * me
+    nv = me.reshape(B, -1).sum(dim=1)
+    if bool((nv == nv[0]).all()):
+        return ((masked.sum() / me.sum()) * w).mean()
+    per = [(masked[i].sum() / nv[i]) * w[i] if nv[i] > 0 else torch.tensor(0.0) for i in range(B)]
+    return torch.stack(per).mean()
+
+
+def model_training_forward(sd: SD, cfg: dict, v_in, v_gt, t, noise, mask=None):
+    """ref models/model.py:158-228: frozen-VAE encode, depth upsample of the conditioning, training_loss."""
+    sf = cfg["scaling_factor"]
+    with torch.no_grad():
+        z_in = vae_encode(sd, v_in, sf, "vae.")
+        z_gt = vae_encode(sd, v_gt, sf, "vae.")
+        z_mask = mask
+        if z_in.shape[2] != z_gt.shape[2]:
+            z_in = F.interpolate(z_in, size=z_gt.shape[2:], mode="trilinear", align_corners=False)
+            if mask is not None:
+                z_mask = F.interpolate(mask.float().unsqueeze(-1).unsqueeze(-1), size=(z_gt.shape[2], 1, 1),
+                                       mode="nearest").squeeze(-1).squeeze(-1)
+    return training_loss(sd, cfg, z_gt, z_in, t, noise, z_mask)
+
+
 def gaussian_window(d: int, h: int, w: int):
     """ref inference/sampler.py:174-198, 455-479"""
     def ax(n):

@@ -230,6 +230,39 @@ with torch.no_grad():
     out["stitch.tiny.out"] = st.numpy()
     out["stitch.gauss_4_16_16"] = DDIMSampler(model.diffusion, model.unet)._create_gaussian_weight(4, 16, 16).numpy()
 
+# 6c. training forward + backward (model.py:158-228 -> diffusion.py:108-203 + autograd): injected t / noise,
+#     full-volume mode (thick depth 2 -> thin depth 6), without a mask and with a variable-depth mask.
+#     Stored: the losses, the L2 norm of every U-Net parameter gradient, and the gradients themselves for the
+#     parameters with <= 30k elements plus one large conv weight.
+v_tr_in = formula_input((2, 1, 2, 32, 32), 18).clamp(-1, 1)
+v_tr_gt = formula_input((2, 1, 6, 32, 32), 19).clamp(-1, 1)
+t_fix = torch.tensor([37, 812])
+mask_var = torch.tensor([[[1., 1., 1., 1., 1., 1.]], [[1., 1., 1., 1., 0., 0.]]])   # (B, 1, T_gt)
+orig_ri, orig_rl = torch.randint, torch.randn_like
+torch.randint = lambda *a, **kw: t_fix.clone()
+torch.randn_like = lambda tt, **kw: formula_noise(-1, tuple(tt.shape))
+try:
+    for tag, mk in (("nomask", None), ("mask", mask_var)):
+        for p_ in model.parameters():
+            p_.grad = None
+            p_.requires_grad_(True)
+        loss, metrics = model(v_tr_in, v_tr_gt, mask=mk)
+        loss.backward()
+        out[f"train.{tag}.loss"] = np.array([loss.item()], dtype=np.float64)
+        names_u, norms = [], []
+        for name_, p_ in model.unet.named_parameters():
+            names_u.append(name_)
+            norms.append(float(p_.grad.double().norm()))
+            if tag == "nomask" and (p_.numel() <= 30000 or name_ == "mid_block1.conv1.conv.weight"):
+                out[f"train.nomask.grad.{name_}"] = p_.grad.numpy().copy()
+        out[f"train.{tag}.grad_norms"] = np.array(norms, dtype=np.float64)
+        out["train.param_names"] = np.array(names_u)
+        assert all(p_.grad is None for p_ in model.vae.parameters()), "VAE must stay frozen (no_grad encode)"
+finally:
+    torch.randint, torch.randn_like = orig_ri, orig_rl
+    for p_ in model.parameters():
+        p_.grad = None
+
 # 7. state-dict layout of the effective production model (names + shapes only, built on `meta`) ----------
 import yaml  # noqa: E402
 cfg_full = yaml.safe_load(open(os.path.join(REF, "config", "slice_interpolation_full_medium.yaml")))

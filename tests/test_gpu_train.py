@@ -1,0 +1,132 @@
+"""GPU: the training forward/backward end to end through the drop-in API:
+`model(v_in, v_gt)` -> loss with an autograd node -> `loss.backward()` -> `.grad` of every U-Net parameter.
+
+Yardstick: the reference computes in fp32, the engine in bf16 storage / fp32 accumulation.  Gradients are compared
+with the fp32 oracle (itself pinned to the reference's autograd by tests/test_oracle_golden.py) and the error is
+held against what the *reference itself* shows when run under PyTorch's CPU bf16 autocast on the same inputs:
+   err_hip(param) <= 2 * err_autocast(param) + 2e-2   (rel-L2 per parameter tensor), loss within 2 %.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+from tests.helpers import formula_input, formula_noise, rel_l2, tiny_model_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T_FIX = torch.tensor([37, 812])
+MASK = torch.tensor([[[1., 1., 1., 1., 1., 1.]], [[1., 1., 1., 1., 0., 0.]]])
+
+
+def _inputs():
+    v_in = formula_input((2, 1, 2, 32, 32), 18).clamp(-1, 1)
+    v_gt = formula_input((2, 1, 6, 32, 32), 19).clamp(-1, 1)
+    noise = formula_noise(-1, (2, 8, 6, 8, 8))
+    return v_in, v_gt, noise
+
+
+def _oracle(sd, cfg, mask, autocast=False):
+    sd = {k: v.clone() for k, v in sd.items()}
+    names = [k for k in sd if k.startswith("unet.")]
+    for k in names:
+        sd[k].requires_grad_(True)
+    v_in, v_gt, noise = _inputs()
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            loss = R.model_training_forward(sd, cfg, v_in, v_gt, T_FIX, noise, mask)
+    else:
+        loss = R.model_training_forward(sd, cfg, v_in, v_gt, T_FIX, noise, mask)
+    loss.float().backward()
+    return float(loss), {k[len("unet."):]: sd[k].grad.float() for k in names}
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+def test_training_step_gradients(golden, pkg, tag):
+    model, sd, cfg = tiny_model_sd(pkg)
+    model.to(DEV)
+    mask = None if tag == "nomask" else MASK
+    v_in, v_gt, noise = _inputs()
+    for p in model.parameters():
+        p.grad = None
+    loss, metrics = model(v_in.to(DEV), v_gt.to(DEV), mask=None if mask is None else mask.to(DEV), t=T_FIX.to(DEV),
+                          noise=noise.to(DEV))
+    assert loss.requires_grad and set(metrics) >= {"loss", "mse", "total"}
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_loss, ref_g = _oracle(sd, cfg, mask)
+    ac_loss, ac_g = _oracle(sd, cfg, mask, autocast=True)
+    gold = float(golden[f"train.{tag}.loss"][0])
+    print(f"[{tag}] loss: hip {loss.item():.6f}  reference {gold:.6f}  reference/bf16-autocast {ac_loss:.6f}")
+    assert abs(ref_loss - gold) <= 2e-5 * abs(gold)
+    assert abs(loss.item() - gold) <= 2e-2 * abs(gold)
+    assert all(p.grad is None for p in model.vae.parameters())
+    worst = []
+    gmax = max(float(g.norm()) for g in ref_g.values())
+    for name, p in model.unet.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, name
+        g = p.grad.float().cpu()
+        if float(ref_g[name].norm()) < 1e-5 * gmax:     # q / k thirds of qkv etc.: (numerically) zero in the reference
+            assert float(g.norm()) <= 1e-3 * gmax, name   # bf16 rounding noise of an analytically zero gradient
+            continue
+        if ".qkv." in name:                              # compare the V third only; q, k are exactly zero here
+            c = p.shape[0] // 3
+            assert float(g[:2 * c].abs().max()) == 0.0
+            e_h, e_a = rel_l2(g[2 * c:], ref_g[name][2 * c:]), rel_l2(ac_g[name][2 * c:], ref_g[name][2 * c:])
+        else:
+            e_h, e_a = rel_l2(g, ref_g[name]), rel_l2(ac_g[name], ref_g[name])
+        worst.append((e_h / (2 * e_a + 2e-2), e_h, e_a, name))
+    worst.sort(reverse=True)
+    for ratio, e_h, e_a, name in worst[:8]:
+        print(f"  {name:50s} hip {e_h:.3e}  autocast {e_a:.3e}")
+    med_h = float(np.median([w[1] for w in worst]))
+    med_a = float(np.median([w[2] for w in worst]))
+    print(f"  median rel-L2 over {len(worst)} tensors: hip {med_h:.3e}, reference under bf16 autocast {med_a:.3e}")
+    assert worst[0][0] <= 1.0, worst[0]
+    if tag == "nomask":   # and directly against the gradients stored from the reference
+        for k in [k for k in golden.files if k.startswith("train.nomask.grad.")]:
+            name = k[len("train.nomask.grad."):]
+            gref = torch.tensor(golden[k])
+            if float(gref.norm()) < 1e-5 * gmax or ".qkv." in name:
+                continue
+            e = rel_l2(model.unet.get_parameter(name).grad.float().cpu(), gref)
+            assert e <= 2 * rel_l2(ac_g[name], gref) + 2e-2, (name, e)
+
+
+def test_optimizer_loop_and_accumulation(pkg):
+    """loss.backward() feeds torch optimizers like the reference: AdamW steps lower the loss on a fixed batch, the
+    engine re-packs the updated weights, gradients accumulate over two backward calls, GradScaler-style scaling of
+    the loss scales the gradients."""
+    model, sd, cfg = tiny_model_sd(pkg)
+    model.to(DEV)
+    v_in, v_gt, noise = (x.to(DEV) for x in _inputs())
+    t = T_FIX.to(DEV)
+    params = [p for p in model.unet.parameters()]
+    opt = torch.optim.AdamW(params, lr=2e-4)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = model(v_in, v_gt, t=t, noise=noise)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        losses.append(loss.item())
+    print("losses:", ["%.5f" % v for v in losses])
+    assert losses[-1] < losses[0]
+    # accumulation + scaling
+    opt.zero_grad(set_to_none=True)
+    loss, _ = model(v_in, v_gt, t=t, noise=noise)
+    loss.backward()
+    g1 = params[0].grad.clone()
+    loss, _ = model(v_in, v_gt, t=t, noise=noise)
+    (loss * 3.0).backward()
+    torch.cuda.synchronize()
+    assert rel_l2(params[0].grad.cpu(), 4.0 * g1.cpu()) <= 2e-2
+    # the drawn-t / drawn-noise path (torch generator) runs and is reproducible under a seed
+    torch.manual_seed(5)
+    la, _ = model(v_in, v_gt)
+    torch.manual_seed(5)
+    lb, _ = model(v_in, v_gt)
+    assert la.item() == lb.item()

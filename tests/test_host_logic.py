@@ -133,8 +133,10 @@ def test_no_cpu_fallback(pkg):
     from inference.generate import generate_batch
     with pytest.raises(ValueError, match="Unknown sampler type"):
         generate_batch(m, x, sampler_type='euler', device='cpu')
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(pkg.CtsiError):      # training forward: HIP engine only, no CPU path
         m(x, x)
+    with pytest.raises(pkg.CtsiError):
+        m.diffusion.training_loss(m.unet, torch.zeros(1, 4, 2, 4, 4), torch.zeros(1, 4, 2, 4, 4))
 
 
 def test_product_does_not_import_oracle():

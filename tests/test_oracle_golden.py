@@ -189,3 +189,37 @@ def test_stitching_depth_ratio_one(golden, pkg):
     assert R.window_starts(24, 16, 8) == [0, 8] and R.window_starts(6, 4, 2) == [0, 2]
     out = R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8), noise_fn=lambda i, shp: formula_noise(-1, shp))
     assert R.psnr(out, torch.tensor(golden["stitch.tiny.out"]), 2.0) > 80.0
+
+
+def _oracle_train(sd, cfg, mask):
+    sd = {k: v.clone() for k, v in sd.items()}
+    names = [k for k in sd if k.startswith("unet.")]
+    for k in names:
+        sd[k].requires_grad_(True)
+    v_in = formula_input((2, 1, 2, 32, 32), 18).clamp(-1, 1)
+    v_gt = formula_input((2, 1, 6, 32, 32), 19).clamp(-1, 1)
+    noise = formula_noise(-1, (2, 8, 6, 8, 8))
+    loss = R.model_training_forward(sd, cfg, v_in, v_gt, torch.tensor([37, 812]), noise, mask)
+    loss.backward()
+    return loss.item(), {k[len("unet."):]: sd[k].grad for k in names}
+
+
+def test_training_forward_backward_vs_reference_autograd(golden, pkg):
+    """The oracle's restatement of model.forward -> training_loss, differentiated by autograd, against the loss and
+    the parameter gradients the reference produced (tests/golden/make_golden.py section 6c)."""
+    _, sd, cfg = tiny_model_sd(pkg)
+    names = [str(n) for n in golden["train.param_names"]]
+    mask = torch.tensor([[[1., 1., 1., 1., 1., 1.]], [[1., 1., 1., 1., 0., 0.]]])
+    for tag, mk in (("nomask", None), ("mask", mask)):
+        loss, grads = _oracle_train(sd, cfg, mk)
+        assert abs(loss - float(golden[f"train.{tag}.loss"][0])) <= 2e-5 * abs(loss)
+        norms = np.array([float(grads[n].double().norm()) for n in names])
+        ref = golden[f"train.{tag}.grad_norms"]
+        big = ref > 1e-6 * ref.max()
+        assert np.allclose(norms[big], ref[big], rtol=2e-3)
+        if tag == "nomask":
+            stored = [k for k in golden.files if k.startswith("train.nomask.grad.")]
+            assert len(stored) > 40
+            for k in stored:
+                g = grads[k[len("train.nomask.grad."):]]
+                assert rel_l2(g, torch.tensor(golden[k])) <= 2e-3 or float(g.abs().max()) < 1e-9, k

@@ -105,6 +105,49 @@ class GaussianDiffusion(nn.Module):
         return run_sampler(self, model, tuple(z_t.shape), c, z_t.device, kind="ddpm", t_desc=[tv[0]],
                            progress=False, z_init=z_t)
 
-    def training_loss(self, *args, **kwargs):
-        raise NotImplementedError("training_loss (reference diffusion.py:108-247) belongs to the training "
-                                  "forward/backward path, which this engine does not cover yet")
+    def training_loss(self, model, z_0, c, mask=None, vae=None, v_gt=None, use_ssim=False, ssim_weight=0.0,
+                      t=None, noise=None):
+        """Min-SNR-5 weighted epsilon-prediction loss (diffusion.py:108-247) with forward AND backward on the HIP
+        engine: the returned scalar carries an autograd node whose backward launches the engine's gradient kernels
+        and feeds the U-Net parameters' .grad.
+
+        t ~ randint(0, T, (B,)) and noise ~ randn_like(z_0) are drawn with torch's generator in the reference's
+        order; `t=` / `noise=` (additive kwargs) inject them instead (tests).  The three normalisations of the
+        reference (no mask; mask with equal valid counts; mask with per-sample counts) are folded into one
+        per-sample factor.  The optional MS-SSIM term needs `pytorch_msssim` and a decode inside the loss; the
+        reference falls back to MSE-only when that import fails, and so does this engine, always."""
+        from .train_engine import UNetTrainProgram, train_step
+        from .engine import Ctx, cached_program
+        if not z_0.is_cuda:
+            raise CtsiError("training_loss runs on the HIP engine: move the tensors to a ROCm device")
+        B, L, d, h, w = z_0.shape
+        device = z_0.device
+        if t is None:
+            t = torch.randint(0, self.timesteps, (B,), device=device, dtype=torch.long)
+        if noise is None:
+            noise = torch.randn_like(z_0)
+        snr = self.alphas_cumprod[t] / (1 - self.alphas_cumprod[t] + 1e-8)
+        snr_weight = torch.clamp(snr, max=5.0) / (snr + 1e-8)
+        if mask is not None:
+            m = mask.to(device=device, dtype=torch.float32)
+            if m.dim() != 3 or m.shape[0] != B or m.shape[2] != d or m.shape[1] not in (1, L):
+                raise ValueError(f"mask must be (B, C, T) = ({B}, 1 or {L}, {d}), got {tuple(m.shape)}")
+            m = m.expand(B, L, d).contiguous()     # mask.unsqueeze(-1).unsqueeze(-1).expand_as(noise_pred)
+            num_valid = m.reshape(B, -1).sum(dim=1) * (h * w)
+            if bool((num_valid == num_valid[0]).all()):
+                norm = (snr_weight.mean() / num_valid.sum()).expand(B)
+            else:
+                norm = torch.where(num_valid > 0, snr_weight / (num_valid.clamp(min=1) * B),
+                                   torch.zeros_like(snr_weight))
+        else:
+            m = None
+            norm = snr_weight / float(B * L * d * h * w)
+        ctx = Ctx.get(device)
+        with ctx.scope():
+            prog = cached_program(model, ("unet-train", ctx.device.index, B, d, h, w),
+                                  lambda: UNetTrainProgram(ctx, model, B, d, h, w))
+            prog.set_diffusion(self)
+        loss = train_step(prog, z_0.detach().float(), c.detach().float(), t, noise.float(), norm, m)
+        loss_dict = {'mse': loss.item()}
+        loss_dict['total'] = loss_dict['mse']
+        return loss, loss_dict

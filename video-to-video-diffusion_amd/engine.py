@@ -75,6 +75,7 @@ class _Pool:
     def __init__(self, device):
         self.device = device
         self.free: Dict[Tuple[int, torch.dtype], List[torch.Tensor]] = {}
+        self.all: List[torch.Tensor] = []   # ops hold raw pointers: every buffer lives as long as the program
         self.total_bytes = 0
 
     def get(self, numel: int, dtype: torch.dtype) -> torch.Tensor:
@@ -82,7 +83,9 @@ class _Pool:
         if lst:
             return lst.pop()
         self.total_bytes += numel * torch.empty(0, dtype=dtype).element_size()
-        return torch.empty(numel, dtype=dtype, device=self.device)
+        t = torch.empty(numel, dtype=dtype, device=self.device)
+        self.all.append(t)
+        return t
 
     def put(self, t: torch.Tensor):
         self.free.setdefault((t.numel(), t.dtype), []).append(t)
@@ -91,12 +94,13 @@ class _Pool:
 class Act:
     """A bf16 NDHWC activation buffer with its logical shape.  In depth-sharded programs (`halo` = 1)
     the buffer holds d + 2 slices: one halo slice below and above the rank's own d slices."""
-    __slots__ = ("t", "n", "c", "d", "h", "w", "halo", "dirty")
+    __slots__ = ("t", "n", "c", "d", "h", "w", "halo", "dirty", "grad")
 
     def __init__(self, t, n, c, d, h, w, halo=0):
         self.t, self.n, self.c, self.d, self.h, self.w = t, n, c, d, h, w
         self.halo = halo
         self.dirty = True  # halo slices stale (they are refreshed lazily, right before a depth-3 conv)
+        self.grad = None   # gradient Act (training programs only)
 
     @property
     def vox(self):

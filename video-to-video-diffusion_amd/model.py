@@ -6,6 +6,7 @@ import logging
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .diffusion import GaussianDiffusion
 from .engine import Ctx, nan_to_num_, trilinear_depth
@@ -72,9 +73,28 @@ class VideoToVideoDiffusion(nn.Module):
     def decode_latent(self, z):
         return self.vae.decode(z)
 
-    def forward(self, v_in, v_gt, mask=None):
-        raise NotImplementedError("the training forward (reference model.py:158-228) is outside the inference "
-                                  "hot path this engine covers")
+    def forward(self, v_in, v_gt, mask=None, t=None, noise=None):
+        """Training forward (model.py:158-228): frozen-VAE encode of both volumes, depth upsample of the
+        conditioning when the depths differ, then `diffusion.training_loss` on the HIP engine.  Returns
+        (loss, metrics); `loss.backward()` runs the engine's backward.  `t=` / `noise=` are test hooks."""
+        if not v_in.is_cuda:
+            raise CtsiError("the training forward runs on the HIP engine: move the inputs to a ROCm device")
+        ctx = Ctx.get(v_in.device)
+        with torch.no_grad():
+            z_in = self.vae.encode(v_in)
+            z_gt = self.vae.encode(v_gt)
+            if z_in.shape[2] != z_gt.shape[2]:
+                with ctx.scope():
+                    z_cond = trilinear_depth(ctx, z_in, int(z_gt.shape[2]))
+                z_mask = None
+                if mask is not None:   # nearest-neighbour pick of the (B, C, T) mask at the latent depth (model.py:205-212)
+                    z_mask = F.interpolate(mask.float().unsqueeze(-1).unsqueeze(-1), size=(z_gt.shape[2], 1, 1),
+                                           mode='nearest').squeeze(-1).squeeze(-1)
+            else:
+                z_cond, z_mask = z_in, mask
+        loss, loss_dict = self.diffusion.training_loss(self.unet, z_gt, z_cond, mask=z_mask, vae=self.vae, v_gt=v_gt,
+                                                       use_ssim=False, ssim_weight=0.0, t=t, noise=noise)
+        return loss, {'loss': loss.item(), **loss_dict}
 
     @torch.no_grad()
     def generate(self, v_in, sampler, num_inference_steps=20, guidance_scale=1.0, target_depth=None,

@@ -52,9 +52,13 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU oracle leg")
-    ap.add_argument("--mode", choices=["dp", "shard"], default="dp",
+    ap.add_argument("--train-hw", type=int, default=192, help="--mode train: slice height/width (192 = config 3)")
+    ap.add_argument("--train-batch", type=int, default=4, help="--mode train: micro-batch per GPU (4 = config 3)")
+    ap.add_argument("--mode", choices=["dp", "shard", "train"], default="dp",
                     help="dp: one volume per GPU, no exchange (weak scaling, BASELINE config 5 style); "
-                         "shard: ONE volume depth-sharded over the GPUs with RCCL halo exchange (strong scaling, config 4)")
+                         "shard: ONE volume depth-sharded over the GPUs with RCCL halo exchange (strong scaling, config 4); "
+                         "train: forward+backward micro-steps of config 3 (frozen-VAE encode + U-Net fwd/bwd), "
+                         "gradients all-reduced over RCCL when N > 1")
     return ap.parse_args()
 
 
@@ -139,6 +143,88 @@ def bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def bench_train(args, pkg, E, model, ctx, dev, rank, world, dist):
+    """Config 3: v_in (B,1,8,hw,hw), v_gt (B,1,48,hw,hw): frozen-VAE encode of both, U-Net forward + backward
+    (models/model.py:158-228).  One timed step = one micro-step (loss.backward() included, no optimizer step, as in
+    the reference's gradient-accumulation loop); data parallel over ranks with a bucketed gradient all-reduce."""
+    P = importlib.import_module("video-to-video-diffusion_amd.parallel")
+    B, hw = args.train_batch, args.train_hw
+    gen = torch.Generator(device="cpu").manual_seed(1 + rank)
+    v_in = (torch.rand(B, 1, args.depth_in, hw, hw, generator=gen) * 2 - 1).to(dev)
+    v_gt = (torch.rand(B, 1, args.depth_out, hw, hw, generator=gen) * 2 - 1).to(dev)
+    params = [p for p in model.unet.parameters()]
+    for p in model.vae.parameters():
+        p.requires_grad_(False)
+
+    def micro_step():
+        for p in params:
+            p.grad = None
+        loss, _ = model(v_in, v_gt)
+        loss.backward()
+        if world > 1:
+            P.allreduce_gradients(params)
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        loss = micro_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = micro_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    finite = bool(torch.isfinite(loss).item()) and all(bool(torch.isfinite(p.grad).all().item()) for p in params[:8])
+    prog = [pr for k, pr in model.unet.__dict__["_ctsi_programs"].items() if k[0] == "unet-train"][0]
+    groups = {}
+    if rank == 0 and not args.no_roofline:
+        with ctx.scope():
+            prof = prog.profile_ops(repeats=1)
+        for i, (name, kern, fl, ms) in enumerate(prof):
+            if kern == "conv_wgrad":
+                key = "wgrad"
+            elif kern.startswith("conv_mfma"):
+                key = "dgrad" if name.endswith(".dgrad") else ("fwd_conv" if i < prog.n_fwd else "bwd_conv_other")
+            else:
+                key = "other_fwd" if i < prog.n_fwd else "other_bwd"
+            g = groups.setdefault(key, [0, 0.0, 0.0])
+            g[0] += 1
+            g[1] += fl
+            g[2] += ms
+    if rank == 0:
+        wg = groups.get("wgrad")
+        roof = None
+        if wg:
+            ach = wg[1] / (wg[2] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_wgrad_kernel (transposing-LDS-read MFMA weight gradient)",
+                    "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                    "traffic": None, "launches_per_step": wg[0], "avg_launch_ms": wg[2] / wg[0],
+                    "groups": {k: {"launches": v[0], "tflops": (v[1] / (v[2] * 1e-3) / 1e12) if v[1] else None,
+                                   "ms": v[2]} for k, v in groups.items()}}
+        print(json.dumps({
+            "metric": "train_microsteps_per_sec", "value": args.steps * world / dt, "unit": "micro-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"config 3 micro-step: v_in ({B},1,{args.depth_in},{hw},{hw}), v_gt ({B},1,"
+                                   f"{args.depth_out},{hw},{hw}); frozen-VAE encode x2 + U-Net forward + backward "
+                                   "(264.66M params), every activation kept in HBM (no recomputation)",
+                       "micro_batch_per_gpu": B, "parallelism": f"dp{world}", "finite": finite,
+                       "samples_per_sec": args.steps * world * B / dt,
+                       "unet_fwd_bwd_tflop": prog.flops / 1e12},
+            "roofline": roof, "cpu_baseline": None}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -169,6 +255,8 @@ def main():
     ctx = E.Ctx.get(dev)
     if args.mode == "shard":
         return bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist)
+    if args.mode == "train":
+        return bench_train(args, pkg, E, model, ctx, dev, rank, world, dist)
     sampler = pkg.DDIMSampler(model.diffusion, model.unet)
     t_desc = [int(t) for t in sampler._get_timesteps(args.ddim_steps)]          # 51 entries for 50 steps
     total = args.warmup + args.steps

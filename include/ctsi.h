@@ -229,14 +229,16 @@ int ctsi_weight_dgrad_layout(const float* w, float* out, int cout, int cin, int 
  * dy: gradient of the output (depth-broadcast (n,1,h,w,c) tensor when dy_bcast_d), sums: the forward's fp64 statistics,
  * residual: the forward's residual input (needed when silu_post).  Writes g_buf = gradient of the GroupNorm output
  * (== gradient of the residual when !silu_pre), dx (+ add when given), dgamma/dbeta (c floats) and, when dtbias is
- * given, dtbias[n][c] (row stride dtbias_stride) = per-sample channel sums of the gradient after the outer SiLU.
+ * given, dtbias[n][c] (row stride dtbias_stride) = per-sample channel sums of the gradient after the outer SiLU, and,
+ * when dxsum is given, dxsum[c] = sum over samples and voxels of dx (before `add`) = the bias gradient of the
+ * convolution that produced x, evaluated in fp32 from the statistics instead of re-reading dx.
  * workspace: ctsi_gn_bwd_workspace_floats() floats. */
 int ctsi_gn_bwd_tiles(int d, int h, int w);
 size_t ctsi_gn_bwd_workspace_floats(int n, int c, int d, int h, int w, int groups);
 int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const double* sums, const float* gamma,
                 const float* beta, int n, int c, int d, int h, int w, int groups, float eps, int silu_pre,
                 const void* residual, int silu_post, const void* add, void* g_buf, void* dx, float* workspace,
-                float* dgamma, float* dbeta, float* dtbias, long long dtbias_stride, void* stream);
+                float* dgamma, float* dbeta, float* dtbias, long long dtbias_stride, float* dxsum, void* stream);
 
 /* out[c] = scale * sum over rows of x[row][c]  (bf16 rows of c_stride channels; conv bias gradients) */
 size_t ctsi_channel_sum_workspace_floats(long long rows, int c);

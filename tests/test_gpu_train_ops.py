@@ -185,11 +185,12 @@ def test_gn_backward_vs_autograd(G, name, c, groups, dims, silu_pre, res, silu_p
         dgam = torch.empty(c, dtype=torch.float32, device=DEV)
         dbet = torch.empty(c, dtype=torch.float32, device=DEV)
         dtb = torch.zeros(n, c + 3, dtype=torch.float32, device=DEV)
+        dxs = torch.empty(c, dtype=torch.float32, device=DEV)
         gam_d, bet_d = gamma.detach().to(DEV), beta.detach().to(DEV)
         cx.lib.gn_bwd(ax.ip, ady.ip, int(bcast), C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), G._ptr(gam_d),
                       G._ptr(bet_d), n, c, d, h, w, groups, 1e-5, int(silu_pre), ar.ip if res else None, int(silu_post),
                       aadd.ip if add else None, G._ptr(gbuf), G._ptr(dx), G._ptr(ws), G._ptr(dgam), G._ptr(dbet),
-                      G._ptr(dtb), c + 3, cx.sptr)
+                      G._ptr(dtb), c + 3, G._ptr(dxs), cx.sptr)
         dx_f = G.from_act(prog, E.Act(dx, n, c, d, h, w))
         g_f = G.from_act(prog, E.Act(gbuf, n, c, d, h, w))
     torch.cuda.synchronize()
@@ -198,6 +199,9 @@ def test_gn_backward_vs_autograd(G, name, c, groups, dims, silu_pre, res, silu_p
     e_g, e_b = rel_l2(dgam.cpu(), gamma.grad), rel_l2(dbet.cpu(), beta.grad)
     print(f"{name}: dx {e_dx:.2e} dgamma {e_g:.2e} dbeta {e_b:.2e}")
     assert e_dx <= 8e-3 and e_g <= 5e-3 and e_b <= 5e-3
+    # bias gradient of the producing conv = sum of dx over samples and voxels (fp32, from the statistics)
+    want_b = x.grad.sum(dim=(0, 2, 3, 4))
+    assert float((dxs.cpu() - want_b).norm()) <= 5e-3 * float(x.grad.abs().sum(dim=(0, 2, 3, 4)).norm())
     if res:
         assert rel_l2(g_f.cpu(), r.grad) <= 8e-3     # g_buf doubles as the residual's gradient
     if not res and not bcast:

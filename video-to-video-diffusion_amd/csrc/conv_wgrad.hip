@@ -20,6 +20,7 @@
 // partial tiles go to a workspace [slice][tap][CRpad][CGpad] fp32 and a second kernel sums the slices in a
 // fixed order into the PyTorch weight-gradient layout (deterministic, no atomics).
 #include "conv3_halo_common.h"
+#include <stdlib.h>
 
 namespace wgk {
 constexpr int BR = 128, BG = 128, BK = 32, NTH = 256;
@@ -197,18 +198,231 @@ conv_wgrad_kernel(const WgradParams p) {
 #endif
 }
 
-// dw[cr*sr + cg*sg + t*st] = sum_s part[s][t][cr][cg]        (fixed summation order)
+// ---- stride-1 'same' convolutions: one block serves the TG taps of a kw row ------------------------------------------
+// For stride 1 and equal R / G grids the gathered voxel of (row voxel v, tap (kd,kh,kw)) is simply
+//   g = v + (kd-pd)*H*W + (kh-ph)*W + (kw-pw)                      (linear voxel indices)
+// so the TG = KW taps of one (kd, kh) read the SAME [32 + TG - 1] consecutive G rows at row shifts 0..TG-1 and the same
+// R slab: 16.5 KB of LDS fill feed 3 taps (190 flop/B instead of 64), and the G slab needs no per-row address decode.
+// Pairs (v, tap) whose true neighbour lies outside the volume (the linear shift wrapped into the next row / slice /
+// sample) are removed by zeroing the k-entries of the B fragment: validity depends on the voxel only, so one wave
+// ballot per tap and K-step yields the masks (skipped when all 32 voxels are valid).
+// Block = 8 waves (2 along R x 4 along G), tile 128 x 128 x TG taps, 96 accumulators per lane for TG = 3.
+namespace wg3 {
+constexpr int BR = 128, BG = 128, BK = 32, NTH = 512;
+constexpr int RSLAB = BK * 256;          // 8 KB
+constexpr int GROWS = 36;                // 32 + up to 3 halo rows, rounded to whole 4-row DMA groups
+constexpr int GSLAB = GROWS * 256;       // 9 KB
+constexpr int STAGE = RSLAB + GSLAB;
+constexpr int NS = 4;                    // LDS stages: the DMA of step s+3 is issued while step s is on the matrix cores
+constexpr int LDS_BYTES = NS * STAGE;
+}  // namespace wg3
+
+__device__ __forceinline__ unsigned wg_pair_mask(unsigned b2) {   // 2 validity bits -> dword mask over 2 bf16
+    return ((b2 & 1u) ? 0x0000ffffu : 0u) | ((b2 & 2u) ? 0xffff0000u : 0u);
+}
+
+template <int TG>
+__global__ void __launch_bounds__(512)
+conv_wgrad_s1_kernel(const WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace wg3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 2, wgc = wv & 3;
+
+    // ---- block decode: tap group fastest, then tiles, then slice ---------------------------------------------------
+    const int ngroups = p.T / TG;
+    int bid = blockIdx.x;
+    const int grp = bid % ngroups;
+    bid /= ngroups;
+    const int tg = bid % p.tiles_g;
+    bid /= p.tiles_g;
+    const int tr = bid % p.tiles_r;
+    const int sl = bid / p.tiles_r;
+    const int kd = grp / p.KH, kh = grp % p.KH;
+    const int k_begin = sl * p.kps;
+    const int k_end = min(k_begin + p.kps, p.ksteps);
+    // linear shift of the group's first tap (kw = 0)
+    const int delta = ((kd - p.pd) * p.Hg + (kh - p.ph)) * p.Wg - p.pw;
+
+    const v4i_t rsR = h3_make_rsrc(p.R, p.r_bytes);
+    const v4i_t rsG = h3_make_rsrc(p.G, p.g_bytes);
+
+    // ---- staging: 8 (R) + 9 (G) wave-DMAs of 4 rows each per K-step; wave w issues R group w, G group w, and wave 0
+    //      also G group 8 --------------------------------------------------------------------------------------------
+    const int lrow = lane >> 4, slot = lane & 15;
+    auto row_col = [&](int row, int tile, int cmax, bool& ok) -> unsigned {
+        const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+        const int ch = slot ^ f;
+        const int c = tile * 128 + ch * 8;
+        ok = c < cmax;
+        return (unsigned)c * 2u;
+    };
+    bool r_ok, g_ok0, g_ok1;
+    const unsigned r_col = row_col(4 * wv + lrow, tr, p.CR, r_ok);
+    const unsigned g_col0 = row_col(4 * wv + lrow, tg, p.CG, g_ok0);
+    const unsigned g_col1 = row_col(32 + lrow, tg, p.CG, g_ok1);
+    const long long g_total = (long long)p.N * p.Dg * p.Hg * p.Wg;
+
+    auto issue = [&](int ks, int stage) {
+        const unsigned base = lds0 + stage * STAGE;
+        const long long v0 = (long long)ks * BK;
+        {
+            const long long v = v0 + 4 * wv + lrow;
+            const unsigned off = (r_ok && v < p.V) ? (unsigned)v * (unsigned)(p.CRs * 2) + r_col : 0xffffffffu;
+            h3_dma16(rsR, base + (4 * wv) * 256, off, 0);
+        }
+        {
+            const long long g = v0 + delta + 4 * wv + lrow;
+            const unsigned off = (g_ok0 && g >= 0 && g < g_total) ? (unsigned)g * (unsigned)(p.CGs * 2) + g_col0 : 0xffffffffu;
+            h3_dma16(rsG, base + RSLAB + (4 * wv) * 256, off, 0);
+        }
+        if (wv == 0 && TG > 1) {
+            const long long g = v0 + delta + 32 + lrow;
+            const unsigned off = (g_ok1 && g >= 0 && g < g_total) ? (unsigned)g * (unsigned)(p.CGs * 2) + g_col1 : 0xffffffffu;
+            h3_dma16(rsG, base + RSLAB + 32 * 256, off, 0);
+        }
+    };
+
+    // ---- transposed-read offsets ---------------------------------------------------------------------------------------
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    unsigned a_off[2][2], b_off[TG][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = 8 * (lane >> 5) + 4 * e + q;
+        const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cha = 4 * (2 * wr + i) + 2 * ((lane >> 4) & 1) + (pp >> 1);
+            a_off[i][e] = (unsigned)(256 * row + 16 * (cha ^ f) + 8 * (pp & 1));
+        }
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            const int rowb = row + t;    // the tap's row shift
+            const int fb = ((rowb & 3) << 2) | ((rowb >> 2) & 3);
+            const int chb = 4 * wgc + 2 * ((lane >> 4) & 1) + (pp >> 1);
+            b_off[t][e] = (unsigned)(RSLAB + 256 * rowb + 16 * (chb ^ fb) + 8 * (pp & 1));
+        }
+    }
+
+    f32x16 acc[TG][2];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.0f;
+
+    static_assert(NS == 4, "the counted vmcnt immediates below assume 2 steps in flight");
+    if (k_begin < k_end) {
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i)
+            if (k_begin + i < k_end) issue(k_begin + i, i);
+        int stage = 0;
+        for (int ks = k_begin; ks < k_end; ++ks) {
+            // step ks must have landed; up to NS-2 later steps may stay in flight (2 DMAs per wave and step, 3 for wave 0)
+            if (ks + NS - 2 < k_end) {
+                if (TG > 1 && wv == 0)
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();   // data of step ks visible to all waves; everyone is done with step ks-1
+            if (ks + NS - 1 < k_end) issue(ks + NS - 1, stage == 0 ? NS - 1 : stage - 1);
+            // validity of (voxel, tap) pairs of this step: lane l decodes voxel 32*ks + (l & 31)
+            unsigned vmask[TG];
+            {
+                const unsigned v = (unsigned)ks * BK + (lane & 31);
+                const unsigned q1 = wg_div(v, p.mW, p.shW);
+                const int w = (int)(v - q1 * p.Wr);
+                const unsigned q2 = wg_div(q1, p.mH, p.shH);
+                const int h = (int)(q1 - q2 * p.Hr);
+                const unsigned nn = wg_div(q2, p.mD, p.shD);
+                const int d = (int)(q2 - nn * p.Dr);
+                const bool dh = v < (unsigned)p.V && (unsigned)(d - p.pd + kd) < (unsigned)p.Dg &&
+                                (unsigned)(h - p.ph + kh) < (unsigned)p.Hg;
+#pragma unroll
+                for (int t = 0; t < TG; ++t)
+                    vmask[t] = (unsigned)__builtin_amdgcn_ballot_w64(dh && (unsigned)(w - p.pw + t) < (unsigned)p.Wg);
+            }
+            const unsigned sb = lds0 + stage * STAGE;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const unsigned so = sb + sub * (16 * 256);
+                bf16x8 af[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const s16x4 a0 = wg_tr_read(so + a_off[i][0]);
+                    const s16x4 a1 = wg_tr_read(so + a_off[i][1]);
+                    af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    const s16x4 b0 = wg_tr_read(so + b_off[t][0]);
+                    const s16x4 b1 = wg_tr_read(so + b_off[t][1]);
+                    bf16x8 bfr = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (vmask[t] != 0xffffffffu) {    // wave-uniform
+                        const unsigned byte = (vmask[t] >> (16 * sub + 8 * (lane >> 5))) & 0xffu;
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        u32x4 m;
+                        m.x = wg_pair_mask(byte);
+                        m.y = wg_pair_mask(byte >> 2);
+                        m.z = wg_pair_mask(byte >> 4);
+                        m.w = wg_pair_mask(byte >> 6);
+                        u32x4 bu = __builtin_bit_cast(u32x4, bfr);
+                        bu &= m;
+                        bfr = __builtin_bit_cast(bf16x8, bu);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[t][i], 0, 0, 0);
+                }
+            }
+            stage = (stage + 1 == NS) ? 0 : stage + 1;
+        }
+    }
+
+    const int CRp = p.tiles_r * BR, CGp = p.tiles_g * BG;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        float* dst = p.part + ((size_t)sl * p.T + grp * TG + t) * (size_t)CRp * CGp;
+        const int cg = tg * BG + 32 * wgc + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = tr * BR + 64 * wr + 32 * i + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                dst[(size_t)cr * CGp + cg] = acc[t][i][r];
+            }
+    }
+#endif
+}
+
+// dw[cr*sr + cg*sg + t*st] = scale * sum_s part[s][t][cr][cg]        (fixed summation order; one thread per output)
 __global__ void __launch_bounds__(256)
 conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T, int CRp, int CGp,
                          int CR, int CG, long long sr, long long sg, long long st, float scale) {
-    const long long total = (long long)CR * CG;
+    const long long total = (long long)T * CR * CG;
+    const size_t slice = (size_t)T * CRp * CGp;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int cr = (int)(e / CG), cg = (int)(e - (long long)cr * CG);
-        for (int t = 0; t < T; ++t) {
-            float s = 0.0f;
-            for (int k = 0; k < S; ++k) s += part[(((size_t)k * T + t) * CRp + cr) * CGp + cg];
-            dw[cr * sr + cg * sg + t * st] = s * scale;
+        const int cg = (int)(e % CG);
+        const long long r = e / CG;
+        const int cr = (int)(r % CR);
+        const int t = (int)(r / CR);
+        const float* src = part + ((size_t)t * CRp + cr) * CGp + cg;
+        float s0 = 0.0f, s1 = 0.0f;
+        int k = 0;
+        for (; k + 1 < S; k += 2) {
+            s0 += src[(size_t)k * slice];
+            s1 += src[(size_t)(k + 1) * slice];
         }
+        if (k < S) s0 += src[(size_t)k * slice];
+        dw[cr * sr + cg * sg + t * st] = (s0 + s1) * scale;
     }
 }
 
@@ -222,6 +436,7 @@ static void wg_magic(unsigned d, unsigned* m, int* sh) {
 
 struct WgradGeom {
     int T, tiles_r, tiles_g, S, ksteps, kps;
+    int tg;   // taps per block: KW for stride-1 'same' layers (conv_wgrad_s1_kernel), 0 = one tap per block (gather kernel)
     long long V;
 };
 
@@ -241,8 +456,13 @@ static int wg_geometry(const ctsi_wgrad_desc* d, WgradGeom* g) {
     g->tiles_r = (d->cr + wgk::BR - 1) / wgk::BR;
     g->tiles_g = (d->cg + wgk::BG - 1) / wgk::BG;
     g->ksteps = (int)((g->V + wgk::BK - 1) / wgk::BK);
-    const int combos = g->T * g->tiles_r * g->tiles_g;
-    int S = (2048 + combos - 1) / combos;          // aim at >= 2048 blocks (256 CUs x 2 x 4)
+    g->tg = 0;
+    if (d->sh == 1 && d->sw == 1 && d->dr == d->dg && d->hr == d->hg && d->wr == d->wg && (d->kw == 3 || d->kw == 1) &&
+        getenv("CTSI_WGRAD_S1"))
+        g->tg = d->kw;   // opt-in: measured 10-20 % slower than the gather kernel on the config-3 shapes (1 block per CU)
+    const int combos = (g->tg ? g->T / g->tg : g->T) * g->tiles_r * g->tiles_g;
+    const int target = g->tg ? 768 : 2048;         // blocks: 256 CUs x 3 (8-wave blocks) / x 8 (4-wave blocks)
+    int S = (target + combos - 1) / combos;
     const int smax = (g->ksteps + 15) / 16;        // at least 16 K-steps (512 voxels) per slice
     if (S > smax) S = smax;
     if (S < 1) S = 1;
@@ -283,13 +503,21 @@ extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* g
     wg_magic((unsigned)d->wr, &p.mW, &p.shW);
     wg_magic((unsigned)d->hr, &p.mH, &p.shH);
     wg_magic((unsigned)d->dr, &p.mD, &p.shD);
-    const long long blocks = (long long)g.T * g.tiles_r * g.tiles_g * g.S;
+    const long long blocks = (long long)(g.tg ? g.T / g.tg : g.T) * g.tiles_r * g.tiles_g * g.S;
     CTSI_CHECK_ARG(blocks < (1ll << 31), "ctsi_wgrad: grid too large");
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(wgk::NTH), wgk::LDS_BYTES, (hipStream_t)stream, p);
+    if (g.tg == 3)
+        hipLaunchKernelGGL(conv_wgrad_s1_kernel<3>, dim3((unsigned)blocks), dim3(wg3::NTH), wg3::LDS_BYTES,
+                           (hipStream_t)stream, p);
+    else if (g.tg == 1)
+        hipLaunchKernelGGL(conv_wgrad_s1_kernel<1>, dim3((unsigned)blocks), dim3(wg3::NTH), wg3::LDS_BYTES,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(wgk::NTH), wgk::LDS_BYTES,
+                           (hipStream_t)stream, p);
     CTSI_LAUNCH_CHECK();
-    const long long total = (long long)d->cr * d->cg;
+    const long long total = (long long)d->cr * d->cg * g.T;
     long long rb = (total + 255) / 256;
-    if (rb > 4096) rb = 4096;
+    if (rb > 8192) rb = 8192;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, dw, g.S, g.T, g.tiles_r * wgk::BR, g.tiles_g * wgk::BG, d->cr, d->cg,
                        stride_r, stride_g, stride_t, scale);

@@ -34,7 +34,7 @@ __device__ __forceinline__ float silu_grad_f(float z) {
 //           g  = gc * (silu_pre ? silu'(h) : 1)    (= grad of h)
 //           dx = rstd * (gamma*g - mean_grp(gamma*g) - xhat * mean_grp(gamma*g*xhat))
 //           dgamma = sum g*xhat, dbeta = sum g.
-// Pass 1 (this kernel): writes g (bf16) and per-tile column sums [n][tiles][3][c] = (sum g, sum g*xhat, sum gc).
+// Pass 1 (this kernel): writes g (bf16) and per-tile column sums [n][tiles][4][c] = (sum g, sum g*xhat, sum gc, sum xhat).
 // grid (tiles, n), block 256.  dy may be a depth-broadcast tensor (n, 1, h, w, c): dy_mod = h*w, else 0.
 __global__ void __launch_bounds__(256)
 gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, long long dy_mod,
@@ -47,7 +47,7 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
     float* s_mr = s_rs + c;                              // -mean*rstd
     float* s_ga = s_mr + c;
     float* s_be = s_ga + c;
-    float* s_red = s_be + c;                             // [rows_par][3][c]
+    float* s_red = s_be + c;                             // [rows_par][4][c]
     const int nb = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const int cpg = c / groups;
     const double cnt = (double)cpg * (double)vox;
@@ -69,9 +69,9 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
     const long long v0 = (long long)tile * GNB_TILE_ROWS;
     long long v1 = v0 + GNB_TILE_ROWS;
     if (v1 > vox) v1 = vox;
-    float a0[8], a1[8], a2[8];
+    float a0[8], a1[8], a2[8], a3[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a0[k] = a1[k] = a2[k] = 0.0f;
+    for (int k = 0; k < 8; ++k) a0[k] = a1[k] = a2[k] = a3[k] = 0.0f;
     if (rl < rows_par) {
         const bf16_t* xb = x + (long long)nb * vox * c + q * 8;
         const bf16_t* rb = residual ? residual + (long long)nb * vox * c + q * 8 : nullptr;
@@ -104,77 +104,120 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
                 a0[k] += g;
                 a1[k] += g * xh;
                 a2[k] += gc;
+                a3[k] += xh;
             }
             *reinterpret_cast<uint4*>(gb + v * c) = t_pack8(gf);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            s_red[(rl * 3 + 0) * c + q * 8 + k] = a0[k];
-            s_red[(rl * 3 + 1) * c + q * 8 + k] = a1[k];
-            s_red[(rl * 3 + 2) * c + q * 8 + k] = a2[k];
+            s_red[(rl * 4 + 0) * c + q * 8 + k] = a0[k];
+            s_red[(rl * 4 + 1) * c + q * 8 + k] = a1[k];
+            s_red[(rl * 4 + 2) * c + q * 8 + k] = a2[k];
+            s_red[(rl * 4 + 3) * c + q * 8 + k] = a3[k];
         }
     }
     __syncthreads();
-    float* out = colsum3 + ((long long)nb * tiles + tile) * 3 * c;
-    for (int e = tid; e < 3 * c; e += 256) {
+    float* out = colsum3 + ((long long)nb * tiles + tile) * 4 * c;
+    for (int e = tid; e < 4 * c; e += 256) {
         float t = 0.0f;
-        for (int r = 0; r < rows_par; ++r) t += s_red[r * 3 * c + e];
+        for (int r = 0; r < rows_par; ++r) t += s_red[r * 4 * c + e];
         out[e] = t;
     }
 }
 
-// Pass 2a: grid n, block 256.  Sums the tiles, forms the group terms, writes per-sample partial parameter grads.
-//   s12[n][groups][2] = (sum_grp gamma*g, sum_grp gamma*g*xhat) / m ;  pgrad[n][3][c] = (sum g*xhat, sum g, sum gc)
+// Pass 2a: grid (group chunks, n), block 256.  A block owns `gpb` whole groups (CB = gpb*cpg <= max(64, cpg)
+// channels) and 256/CB tile lanes; it sums the tiles, forms the group terms and writes per-sample partial grads:
+//   s12[n][groups][2] = (sum_grp gamma*g, sum_grp gamma*g*xhat) / m
+//   pgrad[n][4][c] = (sum g*xhat, sum g, sum gc, sum_v dx)   with  sum_v dx = rstd*(gamma*sum g - V*S1/m - S2/m*sum xhat)
+//   (the last one is the bias gradient of the convolution that produced x)
 __global__ void __launch_bounds__(256)
-gn_bwd_finalize_kernel(const float* __restrict__ colsum3, const float* __restrict__ gamma, int c, long long vox,
-                       int groups, int tiles, float* __restrict__ s12, float* __restrict__ pgrad) {
+gn_bwd_finalize_kernel(const float* __restrict__ colsum3, const float* __restrict__ gamma,
+                       const double* __restrict__ sums, float eps, int c, long long vox, int groups, int tiles,
+                       int gpb, float* __restrict__ s12, float* __restrict__ pgrad) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* s_a = reinterpret_cast<float*>(smem_raw);  // gamma * sum g
-    float* s_b = s_a + c;                              // gamma * sum g*xhat
-    const int nb = blockIdx.x, tid = threadIdx.x;
-    const float* base = colsum3 + (long long)nb * tiles * 3 * c;
-    for (int ch = tid; ch < c; ch += 256) {
-        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
-        for (int t = 0; t < tiles; ++t) {
-            t0 += base[((long long)t * 3 + 0) * c + ch];
-            t1 += base[((long long)t * 3 + 1) * c + ch];
-            t2 += base[((long long)t * 3 + 2) * c + ch];
+    const int cpg = c / groups;
+    const int CB = gpb * cpg;
+    const int TL = CB >= 256 ? 1 : 256 / CB;
+    float* s_part = reinterpret_cast<float*>(smem_raw);   // [TL][4][CB]
+    float* s_tot = s_part + TL * 4 * CB;                   // [4][CB]: sum g, sum g*xhat, sum gc, sum xhat
+    float* s_g1 = s_tot + 4 * CB;                          // [gpb] S1/m
+    float* s_g2 = s_g1 + gpb;
+    const int nb = blockIdx.y, tid = threadIdx.x;
+    const int g0 = blockIdx.x * gpb;
+    const int ngr = min(gpb, groups - g0);
+    const int c0 = g0 * cpg, cn = ngr * cpg;
+    const float* base = colsum3 + (long long)nb * tiles * 4 * c + c0;
+    for (int chl = tid % CB, tl = tid / CB; chl < cn && tl < TL; chl += 256 * ((CB + 255) / 256)) {
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        for (int t = tl; t < tiles; t += TL) {
+            const float* row = base + (long long)t * 4 * c + chl;
+            t0 += row[0];
+            t1 += row[c];
+            t2 += row[2 * c];
+            t3 += row[3 * c];
         }
-        s_a[ch] = gamma[ch] * t0;
-        s_b[ch] = gamma[ch] * t1;
-        pgrad[((long long)nb * 3 + 0) * c + ch] = t1;
-        pgrad[((long long)nb * 3 + 1) * c + ch] = t0;
-        pgrad[((long long)nb * 3 + 2) * c + ch] = t2;
+        s_part[(tl * 4 + 0) * CB + chl] = t0;
+        s_part[(tl * 4 + 1) * CB + chl] = t1;
+        s_part[(tl * 4 + 2) * CB + chl] = t2;
+        s_part[(tl * 4 + 3) * CB + chl] = t3;
+        if (CB <= 256) break;
     }
     __syncthreads();
-    const int cpg = c / groups;
-    const float inv_m = (float)(1.0 / ((double)cpg * (double)vox));
-    for (int g = tid; g < groups; g += 256) {
+    for (int e = tid; e < 4 * CB; e += 256) {
+        const int k = e / CB, chl = e - k * CB;
+        float t = 0.0f;
+        if (chl < cn)
+            for (int tl = 0; tl < TL; ++tl) t += s_part[(tl * 4 + k) * CB + chl];
+        s_tot[e] = t;
+    }
+    __syncthreads();
+    const double cnt = (double)cpg * (double)vox;
+    const float inv_m = (float)(1.0 / cnt);
+    for (int g = tid; g < ngr; g += 256) {
         float sa = 0.0f, sb = 0.0f;
         for (int k = 0; k < cpg; ++k) {
-            sa += s_a[g * cpg + k];
-            sb += s_b[g * cpg + k];
+            const float ga = gamma[c0 + g * cpg + k];
+            sa += ga * s_tot[0 * CB + g * cpg + k];
+            sb += ga * s_tot[1 * CB + g * cpg + k];
         }
-        s12[((long long)nb * groups + g) * 2 + 0] = sa * inv_m;
-        s12[((long long)nb * groups + g) * 2 + 1] = sb * inv_m;
+        s_g1[g] = sa * inv_m;
+        s_g2[g] = sb * inv_m;
+        s12[((long long)nb * groups + g0 + g) * 2 + 0] = sa * inv_m;
+        s12[((long long)nb * groups + g0 + g) * 2 + 1] = sb * inv_m;
+    }
+    __syncthreads();
+    for (int chl = tid; chl < cn; chl += 256) {
+        const int g = chl / cpg, ch = c0 + chl;
+        const double m = sums[((long long)nb * groups + g0 + g) * 2 + 0] / cnt;
+        double var = sums[((long long)nb * groups + g0 + g) * 2 + 1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        pgrad[((long long)nb * 4 + 0) * c + ch] = s_tot[1 * CB + chl];
+        pgrad[((long long)nb * 4 + 1) * c + ch] = s_tot[0 * CB + chl];
+        pgrad[((long long)nb * 4 + 2) * c + ch] = s_tot[2 * CB + chl];
+        pgrad[((long long)nb * 4 + 3) * c + ch] =
+            rstd * (gamma[ch] * s_tot[0 * CB + chl] - (float)vox * s_g1[g] - s_g2[g] * s_tot[3 * CB + chl]);
     }
 }
 
 // Pass 2b: dgamma[c] = sum_n pgrad[n][0][c], dbeta[c] = sum_n pgrad[n][1][c]; dtb[n][c] = pgrad[n][2][c] (optional,
-// row stride dtb_stride)
+// row stride dtb_stride); dxsum[c] = sum_n pgrad[n][3][c] (optional)
 __global__ void __launch_bounds__(256)
 gn_bwd_param_kernel(const float* __restrict__ pgrad, int n, int c, float* __restrict__ dgamma,
-                    float* __restrict__ dbeta, float* __restrict__ dtb, long long dtb_stride) {
+                    float* __restrict__ dbeta, float* __restrict__ dtb, long long dtb_stride,
+                    float* __restrict__ dxsum) {
     const int ch = blockIdx.x * 256 + threadIdx.x;
     if (ch >= c) return;
-    float a = 0.0f, b = 0.0f;
+    float a = 0.0f, b = 0.0f, d = 0.0f;
     for (int i = 0; i < n; ++i) {
-        a += pgrad[((long long)i * 3 + 0) * c + ch];
-        b += pgrad[((long long)i * 3 + 1) * c + ch];
-        if (dtb) dtb[(long long)i * dtb_stride + ch] = pgrad[((long long)i * 3 + 2) * c + ch];
+        a += pgrad[((long long)i * 4 + 0) * c + ch];
+        b += pgrad[((long long)i * 4 + 1) * c + ch];
+        d += pgrad[((long long)i * 4 + 3) * c + ch];
+        if (dtb) dtb[(long long)i * dtb_stride + ch] = pgrad[((long long)i * 4 + 2) * c + ch];
     }
     dgamma[ch] = a;
     dbeta[ch] = b;
+    if (dxsum) dxsum[ch] = d;
 }
 
 // Pass 3: dx = rstd*(gamma*g - S1/m - xhat*S2/m) (+ add).  grid (blocks, n), block 256.
@@ -239,7 +282,7 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
                            const float* beta, int n, int c, int d, int h, int w, int groups, float eps, int silu_pre,
                            const void* residual, int silu_post, const void* add, void* g_buf, void* dx,
                            float* workspace, float* dgamma, float* dbeta, float* dtbias, long long dtbias_stride,
-                           void* stream) {
+                           float* dxsum, void* stream) {
     CTSI_CHECK_ARG(x && dy && sums && gamma && beta && g_buf && dx && workspace && dgamma && dbeta,
                    "ctsi_gn_bwd: null argument");
     CTSI_CHECK_ARG(c % 8 == 0 && c <= 2048 && groups > 0 && c % groups == 0, "ctsi_gn_bwd: bad c=%d groups=%d", c,
@@ -247,14 +290,14 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
     const long long vox = (long long)d * h * w;
     const int tiles = ctsi_gn_bwd_tiles(d, h, w);
     hipStream_t st = (hipStream_t)stream;
-    // workspace: colsum3 [n][tiles][3][c] | s12 [n][groups][2] | pgrad [n][3][c]
+    // workspace: colsum3 [n][tiles][4][c] | s12 [n][groups][2] | pgrad [n][4][c]
     float* colsum3 = workspace;
-    float* s12 = colsum3 + (long long)n * tiles * 3 * c;
+    float* s12 = colsum3 + (long long)n * tiles * 4 * c;
     float* pgrad = s12 + (long long)n * groups * 2;
     const int cpr = c >> 3;
     const int rows_par = 256 / cpr;
     CTSI_CHECK_ARG(rows_par >= 1, "ctsi_gn_bwd: c=%d too wide", c);
-    const size_t lds1 = (size_t)(4 * c + rows_par * 3 * c) * sizeof(float);
+    const size_t lds1 = (size_t)(4 * c + rows_par * 4 * c) * sizeof(float);
     CTSI_CHECK_ARG(lds1 <= 160 * 1024, "ctsi_gn_bwd: LDS budget exceeded for c=%d", c);
     if (lds1 > 64 * 1024)
         CTSI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_bwd_reduce_kernel),
@@ -263,11 +306,20 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
                        dy_bcast_d ? (long long)h * w : 0ll, sums, gamma, beta, c, vox, groups, eps, silu_pre,
                        (const bf16_t*)residual, silu_post, (bf16_t*)g_buf, colsum3, tiles);
     CTSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n), dim3(256), 2 * c * sizeof(float), st, colsum3, gamma, c, vox,
-                       groups, tiles, s12, pgrad);
+    {
+        const int cpg = c / groups;
+        int gpb = 64 / cpg;
+        if (gpb < 1) gpb = 1;
+        if (gpb > groups) gpb = groups;
+        const int CB = gpb * cpg;
+        const int TL = CB >= 256 ? 1 : 256 / CB;
+        const size_t lds2 = (size_t)(TL * 4 * CB + 4 * CB + 2 * gpb) * sizeof(float);
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((groups + gpb - 1) / gpb, n), dim3(256), lds2, st, colsum3, gamma,
+                           sums, eps, c, vox, groups, tiles, gpb, s12, pgrad);
+    }
     CTSI_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, st, pgrad, n, c, dgamma, dbeta, dtbias,
-                       dtbias_stride);
+                       dtbias_stride, dxsum);
     CTSI_LAUNCH_CHECK();
     const long long total = vox * cpr;
     long long blocks = (total + 255) / 256;
@@ -281,7 +333,7 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
 
 extern "C" size_t ctsi_gn_bwd_workspace_floats(int n, int c, int d, int h, int w, int groups) {
     const long long tiles = ctsi_gn_bwd_tiles(d, h, w);
-    return (size_t)((long long)n * tiles * 3 * c + (long long)n * groups * 2 + (long long)n * 3 * c);
+    return (size_t)((long long)n * tiles * 4 * c + (long long)n * groups * 2 + (long long)n * 4 * c);
 }
 
 // ==== channel sums (bias gradients) ==================================================================================
@@ -545,20 +597,28 @@ linear_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy, i
         }
     }
 }
+// grid (in_dim/32, rows): 32 consecutive inputs x 8 output lanes per block, LDS reduction over the lanes
 __global__ void __launch_bounds__(256)
 linear_bwd_x_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy, int rows,
-                    int in_dim, int out_dim, int silu_in, int accumulate, float* __restrict__ dx) {
-    const long long total = (long long)rows * in_dim;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int r = (int)(e / in_dim), i = (int)(e - (long long)r * in_dim);
-        float s = 0.0f;
-        for (int o = 0; o < out_dim; ++o) s += dy[(long long)r * out_dim + o] * w[(long long)o * in_dim + i];
+                    int in_dim, int out_dim, int silu_in, float* __restrict__ dx) {
+    __shared__ float s_red[8][32];
+    const int il = threadIdx.x & 31, ol = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + il, r = blockIdx.y;
+    float s = 0.0f;
+    if (i < in_dim)
+        for (int o = ol; o < out_dim; o += 8) s += dy[(long long)r * out_dim + o] * w[(long long)o * in_dim + i];
+    s_red[ol][il] = s;
+    __syncthreads();
+    if (ol == 0 && i < in_dim) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s_red[k][il];
         if (silu_in) {
-            const float z = x[e];
+            const float z = x[(long long)r * in_dim + i];
             const float sg = 1.0f / (1.0f + expf(-z));
-            s *= sg * (1.0f + z * (1.0f - sg));
+            t *= sg * (1.0f + z * (1.0f - sg));
         }
-        dx[e] = accumulate ? dx[e] + s : s;
+        dx[(long long)r * in_dim + i] = t;
     }
 }
 extern "C" int ctsi_linear_bwd(const float* x, const float* w, const float* dy, int rows, int in_dim, int out_dim,
@@ -573,9 +633,8 @@ extern "C" int ctsi_linear_bwd(const float* x, const float* w, const float* dy, 
         CTSI_LAUNCH_CHECK();
     }
     if (dx) {
-        const long long total = (long long)rows * in_dim;
-        hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
-                           w, dy, rows, in_dim, out_dim, silu_in, 0, dx);
+        hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((in_dim + 31) / 32, rows), dim3(256), 0, (hipStream_t)stream, x, w, dy,
+                           rows, in_dim, out_dim, silu_in, dx);
         CTSI_LAUNCH_CHECK();
     }
     return CTSI_OK;

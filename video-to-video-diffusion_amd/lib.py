@@ -107,7 +107,7 @@ SIGNATURES = {
     "ctsi_gn_bwd_tiles": (_i, [_i, _i, _i], False),
     "ctsi_gn_bwd_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i], False),
     "ctsi_gn_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp, _vp, _vp,
-                         _vp, _vp, _vp, _ll, _vp], True),
+                         _vp, _vp, _vp, _ll, _vp, _vp], True),
     "ctsi_channel_sum_workspace_floats": (_sz, [_ll, _i], False),
     "ctsi_channel_sum": (_i, [_vp, _ll, _i, _i, _vp, _vp, _f, _vp], True),
     "ctsi_add_bf16": (_i, [_vp, _vp, _ll, _vp], True),

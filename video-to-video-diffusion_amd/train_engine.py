@@ -202,7 +202,8 @@ class UNetTrainProgram(Program):
 
     # ---- conv ----------------------------------------------------------------------------------------------------
     def t_conv(self, name, m, x1: Act, x2: Optional[Act], *, transposed=False, k=(3, 3, 3), s=(1, 1), want_stats=False,
-               need_dx=True, f32_out=None, f32_strides=None, gy: Optional[Act] = None, ret_stats=False):
+               need_dx=True, f32_out=None, f32_strides=None, gy: Optional[Act] = None, ret_stats=False,
+               bias_from_gn=False):
         p = (1, 1, 1) if k != (1, 1, 1) else (0, 0, 0)
         cout = m.out_channels
         out, st = self.conv(name, lambda: m.weight, lambda: m.bias, x1, x2, transposed=transposed, k=k, s=s, p=p,
@@ -212,7 +213,8 @@ class UNetTrainProgram(Program):
             g = gy if gy is not None else out.grad
             if g is None:
                 raise CtsiError(f"internal: no gradient reached the output of {name}")
-            self._conv_bwd(name, m.weight, m.bias, x1, x2, g, transposed, k, s, p, cout, need_dx)
+            self._conv_bwd(name, m.weight, None if bias_from_gn else m.bias, x1, x2, g, transposed, k, s, p, cout,
+                           need_dx)
             if gy is None:
                 self.release(out.grad)
                 out.grad = None
@@ -296,7 +298,9 @@ class UNetTrainProgram(Program):
 
     # ---- GroupNorm chain ---------------------------------------------------------------------------------------------
     def t_gn(self, x: Act, slot: int, gn: nn.GroupNorm, *, silu_pre: bool, tb_off: Optional[int] = None,
-             residual: Optional[Act] = None, silu_post: bool = False) -> Act:
+             residual: Optional[Act] = None, silu_post: bool = False, conv_bias: Optional[torch.Tensor] = None) -> Act:
+        """`conv_bias`: bias parameter of the convolution that produced x; its gradient (sum of dx) then comes out of
+        the GroupNorm backward's statistics and that conv's backward skips its own channel-sum pass."""
         out = self.gn_apply(x, slot, gn, silu_pre=silu_pre, tbias=self.tbias if tb_off is not None else None,
                             tbias_off=tb_off or 0, tbias_stride=self.total_out, residual=residual, silu_post=silu_post)
         lib, sptr, prog = self.lib, self.ctx.sptr, self
@@ -307,7 +311,8 @@ class UNetTrainProgram(Program):
             gy = out.grad
             if gy is None:
                 raise CtsiError("internal: no gradient reached a GroupNorm output")
-            self._gn_bwd(x, gy, False, slot, gn, gamma, beta, silu_pre, tb_off, residual, silu_post, None)
+            self._gn_bwd(x, gy, False, slot, gn, gamma, beta, silu_pre, tb_off, residual, silu_post, None,
+                         dxsum=None if conv_bias is None else self.grad_buf(conv_bias))
             self.release(gy)
             out.grad = None
 
@@ -315,7 +320,7 @@ class UNetTrainProgram(Program):
         return out
 
     def _gn_bwd(self, x: Act, gy: Act, bcast: bool, slot: int, gn, gamma, beta, silu_pre, tb_off, residual, silu_post,
-                add: Optional[Act]):
+                add: Optional[Act], dxsum: Optional[torch.Tensor] = None):
         lib, sptr, prog = self.lib, self.ctx.sptr, self
         n, c, d, h, w = x.n, x.c, x.d, x.h, x.w
         groups, eps = gn.num_groups, float(gn.eps)
@@ -342,11 +347,12 @@ class UNetTrainProgram(Program):
         gbp, dxp, dgp, dbp = gbuf.ip, x.grad.ip, _ptr(dgam), _ptr(dbet)
         dtp = C.c_void_p(0 if tb_off is None else self.d_tbias.data_ptr() + 4 * tb_off)
         tstride = self.total_out
+        dxsp = _ptr(dxsum)
 
         def run():
             lib.gn_bwd(xp, gyp, int(bcast), C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, n, c, d, h, w,
                        groups, eps, int(silu_pre), rp, int(silu_post), ap, gbp, dxp, prog._ws_ptr("gn"), dgp, dbp, dtp,
-                       tstride, sptr)
+                       tstride, dxsp, sptr)
 
         self._emit(run, "gn.bwd")
         if add_to_res:
@@ -367,12 +373,12 @@ class UNetTrainProgram(Program):
             r = x
         else:
             r = self.t_conv("res1x1", m.residual_conv, x, skip, k=(1, 1, 1))
-        c1, st = self.t_conv("rb.conv1", m.conv1.conv, x, skip, want_stats=True, ret_stats=True)
+        c1, st = self.t_conv("rb.conv1", m.conv1.conv, x, skip, want_stats=True, ret_stats=True, bias_from_gn=True)
         slot = self.gn_finalize(c1, m.conv1.norm.num_groups, st)
-        h1 = self.t_gn(c1, slot, m.conv1.norm, silu_pre=True, tb_off=self.tb_off[id(m)])
-        c2, st = self.t_conv("rb.conv2", m.conv2[0], h1, None, want_stats=True, ret_stats=True)
+        h1 = self.t_gn(c1, slot, m.conv1.norm, silu_pre=True, tb_off=self.tb_off[id(m)], conv_bias=m.conv1.conv.bias)
+        c2, st = self.t_conv("rb.conv2", m.conv2[0], h1, None, want_stats=True, ret_stats=True, bias_from_gn=True)
         slot = self.gn_finalize(c2, m.conv2[1].num_groups, st)
-        out = self.t_gn(c2, slot, m.conv2[1], silu_pre=False, residual=r, silu_post=True)
+        out = self.t_gn(c2, slot, m.conv2[1], silu_pre=False, residual=r, silu_post=True, conv_bias=m.conv2[0].bias)
         return out
 
     # ---- TemporalAttention in its depth-sum form (see engine.Program.attention) ---------------------------------------------

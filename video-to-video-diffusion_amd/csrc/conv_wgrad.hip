@@ -461,7 +461,8 @@ static int wg_geometry(const ctsi_wgrad_desc* d, WgradGeom* g) {
         getenv("CTSI_WGRAD_S1"))
         g->tg = d->kw;   // opt-in: measured 10-20 % slower than the gather kernel on the config-3 shapes (1 block per CU)
     const int combos = (g->tg ? g->T / g->tg : g->T) * g->tiles_r * g->tiles_g;
-    const int target = g->tg ? 768 : 2048;         // blocks: 256 CUs x 3 (8-wave blocks) / x 8 (4-wave blocks)
+    const int target = g->tg ? 768 : 2048;         // blocks: 256 CUs x 3 (8-wave blocks) / x 8 (4-wave blocks).  Measured: 1024
+                                                   // blocks (half the partial-sum traffic) is 10 % slower end to end (tail balance)
     int S = (target + combos - 1) / combos;
     const int smax = (g->ksteps + 15) / 16;        // at least 16 K-steps (512 voxels) per slice
     if (S > smax) S = smax;

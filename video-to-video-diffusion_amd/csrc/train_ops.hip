@@ -82,31 +82,48 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
         for (int k = 0; k < 8; ++k) {
             rs[k] = s_rs[q * 8 + k]; mr[k] = s_mr[q * 8 + k]; ga[k] = s_ga[q * 8 + k]; be[k] = s_be[q * 8 + k];
         }
-        for (long long v = v0 + rl; v < v1; v += rows_par) {
-            float xf[8], df[8], rf[8], gf[8];
-            t_unpack8(*reinterpret_cast<const uint4*>(xb + v * c), xf);
-            const long long dv = dy_mod ? (v % dy_mod) : v;
-            t_unpack8(*reinterpret_cast<const uint4*>(db + dv * c), df);
-            if (rb) t_unpack8(*reinterpret_cast<const uint4*>(rb + v * c), rf);
+        // 4 voxels per iteration: all 8-12 loads are issued before the first use (memory-level parallelism)
+        constexpr int U = 4;
+        for (long long vb = v0 + rl; vb < v1; vb += (long long)rows_par * U) {
+            uint4 xr[U], dr[U], rr[U];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float xh = xf[k] * rs[k] + mr[k];
-                const float h = xh * ga[k] + be[k];
-                float gc = df[k];
-                if (silu_post) {
-                    float cc = silu_pre ? silu_f(h) : h;
-                    if (rb) cc += rf[k];
-                    gc *= silu_grad_f(cc);
+            for (int u = 0; u < U; ++u) {
+                const long long v = vb + (long long)u * rows_par;
+                if (v < v1) {
+                    xr[u] = *reinterpret_cast<const uint4*>(xb + v * c);
+                    const long long dv = dy_mod ? (v % dy_mod) : v;
+                    dr[u] = *reinterpret_cast<const uint4*>(db + dv * c);
+                    if (rb) rr[u] = *reinterpret_cast<const uint4*>(rb + v * c);
                 }
-                float g = gc;
-                if (silu_pre) g *= silu_grad_f(h);
-                gf[k] = g;
-                a0[k] += g;
-                a1[k] += g * xh;
-                a2[k] += gc;
-                a3[k] += xh;
             }
-            *reinterpret_cast<uint4*>(gb + v * c) = t_pack8(gf);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long v = vb + (long long)u * rows_par;
+                if (v >= v1) break;
+                float xf[8], df[8], rf[8], gf[8];
+                t_unpack8(xr[u], xf);
+                t_unpack8(dr[u], df);
+                if (rb) t_unpack8(rr[u], rf);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float xh = xf[k] * rs[k] + mr[k];
+                    const float h = xh * ga[k] + be[k];
+                    float gc = df[k];
+                    if (silu_post) {
+                        float cc = silu_pre ? silu_f(h) : h;
+                        if (rb) cc += rf[k];
+                        gc *= silu_grad_f(cc);
+                    }
+                    float g = gc;
+                    if (silu_pre) g *= silu_grad_f(h);
+                    gf[k] = g;
+                    a0[k] += g;
+                    a1[k] += g * xh;
+                    a2[k] += gc;
+                    a3[k] += xh;
+                }
+                *reinterpret_cast<uint4*>(gb + v * c) = t_pack8(gf);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {

@@ -278,6 +278,14 @@ int ctsi_blend_accumulate(float* acc, float* wsum, const float* patch, const flo
                           int d0, int h0, int w0, void* stream);
 int ctsi_blend_normalize(float* acc, const float* wsum, long long count, void* stream);
 
+/* validation metrics (utils/metrics.py:14-193) on device: for fp32 (n,c,d,h,w) volumes a, b writes, per depth
+ * slice, out[slice][4] = (mean squared difference, mean SSIM, NaN count of a, NaN count of b) over (n,c,h,w).
+ * SSIM = the reference's avg_pool2d box-window form (window odd <= 15, zeros counted at the borders, variances
+ * clamped at 0, map clamped to [0,1]); PSNR = 20 log10(max_val / sqrt(max(mse, 1e-8))) is left to the caller. */
+size_t ctsi_slice_metrics_workspace_doubles(int n, int c, int d, int h, int w);
+int ctsi_slice_metrics(const float* a, const float* b, int n, int c, int d, int h, int w, int window, float max_val,
+                       double* workspace, double* out, void* stream);
+
 /* hipMemsetAsync on the engine stream (zeroing GroupNorm accumulators / padded channels);
  * capturable as a memset node.                                                              */
 int ctsi_memset_async(void* ptr, int value, size_t bytes, void* stream);

@@ -386,6 +386,22 @@ def ddim_stitched(sd: SD, cfg: dict, v_full, n_steps: int, patch, stride, noise_
     return acc / (wmap + 1e-8)
 
 
+def ssim_box(a, b, window: int = 11, max_val: float = 1.0) -> float:
+    """ref utils/metrics.py:48-121 for (B,C,H,W) inputs; (B,C,D,H,W) = mean over slices."""
+    if a.ndim == 5:
+        vals = [ssim_box(a[:, :, i], b[:, :, i], window, max_val) for i in range(a.shape[2])]
+        return sum(vals) / len(vals) if vals else 0.0
+    c1, c2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
+    pool = lambda t: F.avg_pool2d(t, window, stride=1, padding=window // 2)
+    mu1, mu2 = pool(a), pool(b)
+    v1 = torch.clamp(pool(a * a) - mu1 * mu1, min=0.0)
+    v2 = torch.clamp(pool(b * b) - mu2 * mu2, min=0.0)
+    v12 = pool(a * b) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + c1) * (2 * v12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (v1 + v2 + c2) + 1e-8)
+    m = torch.clamp(m, 0.0, 1.0)
+    return 0.0 if bool(torch.isnan(m).any()) else float(m.mean())
+
+
 def psnr(a, b, max_val: float) -> float:
     """ref utils/metrics.py:14-44"""
     mse = torch.clamp(torch.mean((a - b) ** 2), min=1e-8)

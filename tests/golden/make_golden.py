@@ -263,6 +263,19 @@ finally:
     for p_ in model.parameters():
         p_.grad = None
 
+# 6d. validation metrics (utils/metrics.py): PSNR / box-window SSIM per frame and overall
+m_a = formula_input((2, 1, 5, 40, 36), 21).clamp(-1, 1)
+m_b = (m_a + 0.15 * formula_input((2, 1, 5, 40, 36), 22)).clamp(-1, 1)
+vm = ref_metrics.calculate_video_metrics(m_a, m_b, max_val=2.0)
+out["metrics.psnr_per_frame"] = np.array(vm["psnr_per_frame"], dtype=np.float64)
+out["metrics.ssim_per_frame"] = np.array(vm["ssim_per_frame"], dtype=np.float64)
+out["metrics.mean"] = np.array([vm["psnr"], vm["ssim"]], dtype=np.float64)
+out["metrics.psnr_all"] = np.array([ref_metrics.calculate_psnr(m_a, m_b, max_val=2.0)], dtype=np.float64)
+out["metrics.ssim_5d"] = np.array([ref_metrics.calculate_ssim(m_a, m_b, max_val=2.0)], dtype=np.float64)
+out["metrics.ssim_4d_w7"] = np.array([ref_metrics.calculate_ssim(m_a[:, :, 0], m_b[:, :, 0], window_size=7, max_val=1.0)],
+                                     dtype=np.float64)
+out["metrics.psnr_identical"] = np.array([ref_metrics.calculate_psnr(m_a, m_a, max_val=2.0)], dtype=np.float64)
+
 # 7. state-dict layout of the effective production model (names + shapes only, built on `meta`) ----------
 import yaml  # noqa: E402
 cfg_full = yaml.safe_load(open(os.path.join(REF, "config", "slice_interpolation_full_medium.yaml")))

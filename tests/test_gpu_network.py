@@ -247,3 +247,31 @@ def test_sample_with_stitching(golden, pkg):
         a2[:, :, d0:d0 + 3, h0:h0 + 4, w0:w0 + 5] += patch.cpu() * win
         w2[:, :, d0:d0 + 3, h0:h0 + 4, w0:w0 + 5] += win
     assert torch.allclose(acc.cpu(), a2 / (w2 + 1e-8), rtol=1e-6, atol=1e-7)
+
+
+def test_device_metrics_vs_reference(golden, pkg):
+    """utils.metrics drop-in: PSNR / SSIM per frame on device against the values the reference computed."""
+    from utils.metrics import calculate_psnr, calculate_ssim, calculate_video_metrics
+    a = formula_input((2, 1, 5, 40, 36), 21).clamp(-1, 1)
+    b = (a + 0.15 * formula_input((2, 1, 5, 40, 36), 22)).clamp(-1, 1)
+    ad, bd = a.to(DEV), b.to(DEV)
+    vm = calculate_video_metrics(ad, bd, max_val=2.0)
+    assert np.allclose(vm["psnr_per_frame"], golden["metrics.psnr_per_frame"], atol=1e-4)
+    assert np.allclose(vm["ssim_per_frame"], golden["metrics.ssim_per_frame"], atol=2e-6)
+    assert abs(vm["psnr"] - golden["metrics.mean"][0]) < 1e-4 and abs(vm["ssim"] - golden["metrics.mean"][1]) < 2e-6
+    assert abs(calculate_psnr(ad, bd, max_val=2.0) - golden["metrics.psnr_all"][0]) < 1e-4
+    assert abs(calculate_ssim(ad, bd, max_val=2.0) - golden["metrics.ssim_5d"][0]) < 2e-6
+    assert abs(calculate_ssim(ad[:, :, 0], bd[:, :, 0], window_size=7, max_val=1.0) - golden["metrics.ssim_4d_w7"][0]) < 2e-6
+    # identical inputs: the MSE floor of 1e-8 caps the PSNR at 20 log10(max_val / 1e-4) (86.02 dB for max_val 2)
+    assert abs(calculate_psnr(ad, ad, max_val=2.0) - golden["metrics.psnr_identical"][0]) < 1e-5
+    bad = bd.clone()
+    bad[0, 0, 2, 3, 4] = float("nan")
+    assert calculate_video_metrics(ad, bad, max_val=2.0) == {'psnr': 0.0, 'ssim': 0.0, 'psnr_per_frame': [], 'ssim_per_frame': []}
+    with pytest.raises(pkg.CtsiError):
+        calculate_psnr(a, b)
+    # (C,T,H,W) input and a volume-sized case against the oracle
+    big_a = formula_input((1, 1, 6, 200, 168), 23).clamp(-1, 1)
+    big_b = (big_a + 0.05 * formula_input((1, 1, 6, 200, 168), 24)).clamp(-1, 1)
+    vm2 = calculate_video_metrics(big_a[0].to(DEV), big_b[0].to(DEV), max_val=2.0)
+    assert abs(vm2["ssim"] - R.ssim_box(big_a, big_b, 11, 2.0)) < 2e-6
+    assert abs(vm2["psnr"] - np.mean([R.psnr(big_a[:, :, i], big_b[:, :, i], 2.0) for i in range(6)])) < 1e-4

@@ -175,3 +175,42 @@ def test_gaussian_blend_window(pkg):
                           torch.exp(-(z[0] ** 2) / (2 * (4 / 6) ** 2)))
     assert S._window_starts(512, 192, 96) == [0, 96, 192, 288, 320]
     assert S._window_starts(8, 8, 4) == [0]
+
+
+def test_utils_dropin_checkpoint_helpers(tmp_path, pkg):
+    """utils.checkpoint drop-in (reference utils/checkpoint.py): discovery rules, suffix parsing, round trip through
+    VideoToVideoDiffusion.save_checkpoint / load_model_from_checkpoint (strict state-dict layout)."""
+    import os
+    import time
+    from utils import setup_logger, calculate_psnr, calculate_ssim  # noqa: F401  (reference utils/__init__.py surface)
+    from utils import checkpoint as ck
+    from tests.helpers import TINY_CFG
+    assert ck.extract_model_suffix_from_path("a/checkpoint_best_epoch_24_slice_interp_full3.pt") == "slice_interp_full3"
+    assert ck.extract_model_suffix_from_path("checkpoint_final_epoch_3.pt") is None
+    assert ck.find_best_checkpoint(str(tmp_path / "missing")) is None and ck.list_all_checkpoints(str(tmp_path / "missing")) == []
+    assert ck.find_latest_checkpoint(str(tmp_path)) is None
+    m = pkg.VideoToVideoDiffusion(TINY_CFG)
+    for name in ("checkpoint_best_epoch_1_run.pt", "checkpoint_best_epoch_2_run.pt", "checkpoint_best_epoch_2.pt"):
+        m.save_checkpoint(str(tmp_path / name), epoch=int(name.split("_")[3].split(".")[0]), best_loss=0.5)
+        time.sleep(0.01)
+    assert os.path.basename(ck.find_best_checkpoint(str(tmp_path), "run")) == "checkpoint_best_epoch_2_run.pt"
+    assert os.path.basename(ck.find_latest_checkpoint(str(tmp_path), "run")) == "checkpoint_best_epoch_2_run.pt"
+    m.save_checkpoint(str(tmp_path / "checkpoint_final_epoch_9_run.pt"), epoch=9)
+    assert os.path.basename(ck.find_latest_checkpoint(str(tmp_path), "run")) == "checkpoint_final_epoch_9_run.pt"
+    assert len(ck.list_all_checkpoints(str(tmp_path))) == 4 and len(ck.list_all_checkpoints(str(tmp_path), "run")) == 3
+    assert os.path.basename(ck.list_all_checkpoints(str(tmp_path))[0]) == "checkpoint_final_epoch_9_run.pt"
+    m2 = pkg.VideoToVideoDiffusion(TINY_CFG)
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.add_(1.0)
+    m2, meta = ck.load_model_from_checkpoint(m2, str(tmp_path / "checkpoint_best_epoch_2_run.pt"), device="cpu")
+    assert meta["epoch"] == 2 and meta["best_loss"] == 0.5 and meta["config"] == TINY_CFG and not m2.training
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    torch.save(m.state_dict(), tmp_path / "bare.pt")                     # old format: a bare state dict
+    _, meta = ck.load_model_from_checkpoint(pkg.VideoToVideoDiffusion(TINY_CFG), str(tmp_path / "bare.pt"), device="cpu")
+    assert meta == {}
+    with pytest.raises(FileNotFoundError):
+        ck.load_checkpoint(str(tmp_path / "nope.pt"))
+    log = setup_logger("ctsi_test", log_file=str(tmp_path / "logs" / "x.log"))
+    log.info("hello")
+    assert "hello" in open(tmp_path / "logs" / "x.log").read()

@@ -223,3 +223,14 @@ def test_training_forward_backward_vs_reference_autograd(golden, pkg):
             for k in stored:
                 g = grads[k[len("train.nomask.grad."):]]
                 assert rel_l2(g, torch.tensor(golden[k])) <= 2e-3 or float(g.abs().max()) < 1e-9, k
+
+
+def test_metrics_vs_reference(golden):
+    a = formula_input((2, 1, 5, 40, 36), 21).clamp(-1, 1)
+    b = (a + 0.15 * formula_input((2, 1, 5, 40, 36), 22)).clamp(-1, 1)
+    for i in range(5):
+        assert abs(R.psnr(a[:, :, i], b[:, :, i], 2.0) - golden["metrics.psnr_per_frame"][i]) < 1e-4
+        assert abs(R.ssim_box(a[:, :, i], b[:, :, i], 11, 2.0) - golden["metrics.ssim_per_frame"][i]) < 1e-6
+    assert abs(R.psnr(a, b, 2.0) - golden["metrics.psnr_all"][0]) < 1e-4
+    assert abs(R.ssim_box(a, b, 11, 2.0) - golden["metrics.ssim_5d"][0]) < 1e-6
+    assert abs(R.ssim_box(a[:, :, 0], b[:, :, 0], 7, 1.0) - golden["metrics.ssim_4d_w7"][0]) < 1e-6

@@ -390,3 +390,108 @@ extern "C" int ctsi_blend_normalize(float* acc, const float* wsum, long long cou
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }
+
+// ---- validation metrics (utils/metrics.py:14-193): per-slice MSE and 11x11 box-window SSIM on device ---------------
+// a, b: fp32 (n, c, d, h, w).  SSIM as the reference writes it: means / second moments are avg_pool2d(window,
+// stride 1, padding window/2, zeros counted) of a, b, a^2, b^2, ab; variances clamped at 0; map clamped to [0, 1].
+// grid (tiles_w, tiles_h, n*c*d), block 16x16 outputs, (16+2R)^2 input tile of a and b in LDS (R <= 7).
+// Per-block partials (sum of squared differences, sum of SSIM, NaN counts) go to a workspace; a second kernel adds
+// them per slice in a fixed order.
+#define MET_T 16
+#define MET_RMAX 7
+__global__ void __launch_bounds__(256)
+slice_metrics_kernel(const float* __restrict__ a, const float* __restrict__ b, int d, int h, int w, int R, float c1,
+                     float c2, double* __restrict__ partial) {
+    __shared__ float s_a[MET_T + 2 * MET_RMAX][MET_T + 2 * MET_RMAX + 1];
+    __shared__ float s_b[MET_T + 2 * MET_RMAX][MET_T + 2 * MET_RMAX + 1];
+    __shared__ double s_red[4][256];
+    const int plane = blockIdx.z;                    // (n*c + ch)*d + slice
+    const int x0 = blockIdx.x * MET_T, y0 = blockIdx.y * MET_T;
+    const float* pa = a + (long long)plane * h * w;
+    const float* pb = b + (long long)plane * h * w;
+    const int TS = MET_T + 2 * R;
+    for (int e = threadIdx.x; e < TS * TS; e += 256) {
+        const int ty = e / TS, tx = e - ty * TS;
+        const int y = y0 + ty - R, x = x0 + tx - R;
+        const bool in = y >= 0 && y < h && x >= 0 && x < w;
+        s_a[ty][tx] = in ? pa[(long long)y * w + x] : 0.0f;
+        s_b[ty][tx] = in ? pb[(long long)y * w + x] : 0.0f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % MET_T, ly = threadIdx.x / MET_T;
+    const int x = x0 + lx, y = y0 + ly;
+    double sq = 0.0, ss = 0.0, na = 0.0, nb = 0.0;
+    if (x < w && y < h) {
+        float sa = 0.0f, sb = 0.0f, saa = 0.0f, sbb = 0.0f, sab = 0.0f;
+        for (int j = 0; j <= 2 * R; ++j)
+            for (int i = 0; i <= 2 * R; ++i) {
+                const float va = s_a[ly + j][lx + i], vb = s_b[ly + j][lx + i];
+                sa += va; sb += vb; saa += va * va; sbb += vb * vb; sab += va * vb;
+            }
+        const float inv = 1.0f / (float)((2 * R + 1) * (2 * R + 1));
+        const float mu1 = sa * inv, mu2 = sb * inv;
+        float v1 = saa * inv - mu1 * mu1, v2 = sbb * inv - mu2 * mu2;
+        const float v12 = sab * inv - mu1 * mu2;
+        v1 = fmaxf(v1, 0.0f);
+        v2 = fmaxf(v2, 0.0f);
+        const float num = (2.0f * mu1 * mu2 + c1) * (2.0f * v12 + c2);
+        const float den = (mu1 * mu1 + mu2 * mu2 + c1) * (v1 + v2 + c2) + 1e-8f;
+        float s = num / den;
+        s = fminf(fmaxf(s, 0.0f), 1.0f);     // NaN stays NaN through fminf/fmaxf? no: they drop NaN -> counted below
+        const float ca = s_a[ly + R][lx + R], cb = s_b[ly + R][lx + R];
+        const float df = ca - cb;
+        sq = (double)df * (double)df;
+        ss = (double)s;
+        na = (ca != ca) ? 1.0 : 0.0;
+        nb = (cb != cb) ? 1.0 : 0.0;
+    }
+    s_red[0][threadIdx.x] = sq; s_red[1][threadIdx.x] = ss; s_red[2][threadIdx.x] = na; s_red[3][threadIdx.x] = nb;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int k = 0; k < 4; ++k) s_red[k][threadIdx.x] += s_red[k][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const long long blk = ((long long)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[blk * 4 + threadIdx.x] = s_red[threadIdx.x][0];
+    }
+}
+// out[slice][4] = (mean squared difference, mean SSIM, NaN count of a, NaN count of b) over (n, c, h, w)
+__global__ void slice_metrics_final_kernel(const double* __restrict__ partial, int nc, int d, long long tiles, long long hw,
+                                           double* __restrict__ out) {
+    const int sl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sl >= d) return;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int p = 0; p < nc; ++p) {
+        const double* src = partial + ((long long)p * d + sl) * tiles * 4;
+        for (long long t = 0; t < tiles; ++t)
+            for (int k = 0; k < 4; ++k) acc[k] += src[t * 4 + k];
+    }
+    const double cnt = (double)nc * (double)hw;
+    out[sl * 4 + 0] = acc[0] / cnt;
+    out[sl * 4 + 1] = acc[1] / cnt;
+    out[sl * 4 + 2] = acc[2];
+    out[sl * 4 + 3] = acc[3];
+}
+extern "C" size_t ctsi_slice_metrics_workspace_doubles(int n, int c, int d, int h, int w) {
+    const long long tiles = (long long)((h + MET_T - 1) / MET_T) * ((w + MET_T - 1) / MET_T);
+    return (size_t)((long long)n * c * d * tiles * 4);
+}
+extern "C" int ctsi_slice_metrics(const float* a, const float* b, int n, int c, int d, int h, int w, int window,
+                                  float max_val, double* workspace, double* out, void* stream) {
+    CTSI_CHECK_ARG(a && b && workspace && out && n > 0 && c > 0 && d > 0 && h > 0 && w > 0, "ctsi_slice_metrics: bad arguments");
+    CTSI_CHECK_ARG(window >= 1 && (window & 1) && window / 2 <= MET_RMAX, "ctsi_slice_metrics: window must be odd and <= %d",
+                   2 * MET_RMAX + 1);
+    const long long planes = (long long)n * c * d;
+    CTSI_CHECK_ARG(planes <= 65535, "ctsi_slice_metrics: too many (n, c, d) planes for one launch (%lld)", planes);
+    const dim3 grid((w + MET_T - 1) / MET_T, (h + MET_T - 1) / MET_T, (unsigned)planes);
+    const float c1 = (0.01f * max_val) * (0.01f * max_val), c2 = (0.03f * max_val) * (0.03f * max_val);
+    hipLaunchKernelGGL(slice_metrics_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, b, d, h, w, window / 2, c1, c2,
+                       workspace);
+    CTSI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slice_metrics_final_kernel, dim3((d + 63) / 64), dim3(64), 0, (hipStream_t)stream, workspace, n * c, d,
+                       (long long)grid.x * grid.y, (long long)h * w, out);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}

@@ -120,6 +120,8 @@ SIGNATURES = {
     "ctsi_linear_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp], True),
     "ctsi_blend_accumulate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_blend_normalize": (_i, [_vp, _vp, _ll, _vp], True),
+    "ctsi_slice_metrics_workspace_doubles": (_sz, [_i, _i, _i, _i, _i], False),
+    "ctsi_slice_metrics": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], True),
     "ctsi_memset_async": (_i, [_vp, _i, _sz, _vp], True),
     "ctsi_graph_begin_capture": (_i, [_vp], True),
     "ctsi_graph_end_capture": (_i, [_vp, C.POINTER(_vp)], True),

@@ -58,6 +58,17 @@ def _worker(rank, world, port, out_dir):
         local = torch.stack([torch.full((2, 2), float(u)) for u in units])
         allv = P.gather_units(local, counts)
         assert allv[:, 0, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+        # data-parallel training: bucketed gradient all-reduce (ragged tensors, several buckets, averaged)
+        params = [torch.nn.Parameter(torch.zeros(shape)) for shape in ((7, 3), (5,), (2, 2, 2), (1,), (33,))]
+        for i, p_ in enumerate(params):
+            p_.grad = torch.full(p_.shape, float((rank + 1) * (i + 1)))
+        params.append(torch.nn.Parameter(torch.zeros(3)))        # a parameter without gradient is skipped
+        nb = P.allreduce_gradients(params, bucket_bytes=64)
+        assert nb >= 3
+        mean_rank = sum(range(1, world + 1)) / world
+        for i, p_ in enumerate(params[:-1]):
+            assert torch.allclose(p_.grad, torch.full(p_.shape, mean_rank * (i + 1))), (rank, i)
+        assert params[-1].grad is None
         with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
             f.write("ok")
     finally:

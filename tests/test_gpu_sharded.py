@@ -59,8 +59,11 @@ def test_sharded_unet_step_matches_unsharded(pkg, cfg, shape, world):
     # differ by the same 1.3e-2 on this net), so the network-level bound is the bf16 tolerance; the
     # bit-level check of the exchange itself is test_sharded_conv_chain_bit_exact below.
     assert rel_l2(eps, eps_ref) < 3e-2, rel_l2(eps, eps_ref)
-    assert rel_l2(z1, z1_ref) < 8e-2       # step 0 (t=999) amplifies by ~1e4 and clamps
-    assert rel_l2(z2, z2_ref) < 8e-2
+    # step 0 (t=999) divides by 1e-4 and clamps 99.9 % of z0 to +-10: a bf16-level change of
+    # eps flips the sign of a clamped element (error 20 on a value of ~7).  0.15 rel-L2 = at most ~0.5 % of the
+    # elements flipped; the eps bound above is the numerical check, this one guards the update plumbing.
+    assert rel_l2(z1, z1_ref) < 0.15
+    assert rel_l2(z2, z2_ref) < 0.15
 
 
 @pytest.mark.parametrize("world", [2, 4])

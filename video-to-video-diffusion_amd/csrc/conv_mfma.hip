@@ -676,6 +676,11 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             // persistent-block variant: measured slower than the one-tile-per-block kernel (its register epilogue
             // issues 64 two-byte stores per wave, 0.084 ms of a 0.85 ms layer) -> opt-in only, see profiles/r01_notes.md
             if (p->halo3 == 2 && getenv("CTSI_CONV_PERSIST") && !getenv("CTSI_CONV_NO_PERSIST")) p->halo3 = 3;
+            // half-size blocks (4 waves, 64 couts, 16-channel chunks, two blocks per CU): conv3_halo_n64.hip
+            if (p->halo3 == 2 && getenv("CTSI_CONV_N64")) {
+                p->halo3 = 4;
+                p->BN = 64;
+            }
         }
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
@@ -749,6 +754,7 @@ extern "C" int ctsi_conv_plan_set_weight_cin(ctsi_conv_plan* p, int cin_w) {
 extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float* w, void* packed,
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
+    if (p->halo3 == 4) return ctsi_conv3_halo_n64_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
     if (p->halo3) return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
     PackParams q;
     memset(&q, 0, sizeof(q));
@@ -831,7 +837,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         h.dshift = p->dshift;
         h.tilesD = p->tilesD; h.tilesH = p->tilesH; h.tilesW = p->tilesW; h.tps = p->tps; h.mtiles = p->mtiles;
         h.ntiles_n = p->ntiles_n;
-        h.nchunks = p->Cin / 32;
+        h.nchunks = p->Cin / (p->halo3 == 4 ? 16 : 32);
         h.Cout = p->d.cout; h.CoutPad = p->CoutPad;
         h.cout_stride = o->cout_stride; h.c_off = o->c_off;
         {
@@ -840,6 +846,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
         }
+        if (p->halo3 == 4) return ctsi_conv3_halo_n64_launch(&h, stream);
         if (p->halo3 == 3) {
             static int ncu = 0;
             if (!ncu) {

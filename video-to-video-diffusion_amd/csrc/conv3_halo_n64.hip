@@ -210,8 +210,9 @@ conv3_halo32n_kernel(const Conv3HaloParams p) {
         const int vs = va + (kd * HH + kh) * HW;
         HN_PHASE(fa0, fb0, fa2, fb2, hbuf, wbuf, vs, 2);
         // slot s is drained by this wave once the loads above have returned.  Needed next: weights of step s+1
-        // (issued 3 steps ago) and, at a chunk switch, the whole next halo (last pieces issued at g = 6).
-        hn_wait_vm(g >= 7 ? 0 : n_prev1 + n_prev2);
+        // (issued 3 steps ago) and, before the chunk switch (g = 8), the whole next halo: its last piece was issued at
+        // g = 6, and the only DMAs issued after it are the weights of step g = 7 -> those alone may stay in flight.
+        hn_wait_vm(g == 8 ? n_prev1 : n_prev1 + n_prev2);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         int issued = 0;

@@ -130,3 +130,51 @@ def test_optimizer_loop_and_accumulation(pkg):
     torch.manual_seed(5)
     lb, _ = model(v_in, v_gt)
     assert la.item() == lb.item()
+
+
+def test_training_loss_latent4_three_levels(pkg):
+    """The 163 M-variant's shape family (latent_dim 4 -> 8-channel padded input / output-gradient tensors, 3 levels,
+    attention at two levels, 8 heads, odd spatial sizes at the coarsest level) straight through
+    GaussianDiffusion.training_loss, against the oracle's autograd."""
+    from tests.helpers import MID_UNET, load_formula, unet_cfg
+    un = pkg.UNet3D(**MID_UNET)
+    load_formula(un, 9)
+    sd = {"unet." + k: v.detach().clone() for k, v in un.state_dict().items()}
+    diff = pkg.GaussianDiffusion('cosine', 1000)
+    for k, v in diff.state_dict().items():
+        sd["diffusion." + k] = v
+    un.to(DEV)
+    diff.to(DEV)
+    shape = (3, 4, 5, 12, 8)
+    z0, cond, noise = formula_input(shape, 31), formula_input(shape, 32), formula_noise(-1, shape)
+    t = torch.tensor([5, 400, 990])
+    loss, ld = diff.training_loss(un, z0.to(DEV), cond.to(DEV), t=t.to(DEV), noise=noise.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    names = [k for k in sd if k.startswith("unet.")]
+    for k in names:
+        sd[k].requires_grad_(True)
+    cfg = unet_cfg(MID_UNET)
+    ref = R.training_loss(sd, cfg, z0, cond, t, noise)
+    ref.backward()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        sd2 = {k: v.detach().clone().requires_grad_(k.startswith("unet.")) for k, v in sd.items()}
+        ac = R.training_loss(sd2, cfg, z0, cond, t, noise)
+    ac.float().backward()
+    print(f"latent-4 loss: hip {loss.item():.6f} oracle {ref.item():.6f} autocast {float(ac):.6f}")
+    assert abs(loss.item() - ref.item()) <= 2e-2 * abs(ref.item()) and ld["total"] == ld["mse"]
+    gmax = max(float(sd[k].grad.norm()) for k in names)
+    worst = 0.0
+    for name, p in un.named_parameters():
+        gref, gac = sd["unet." + name].grad, sd2["unet." + name].grad.float()
+        g = p.grad.float().cpu()
+        if float(gref.norm()) < 1e-5 * gmax:
+            assert float(g.norm()) <= 1e-3 * gmax, name
+            continue
+        if ".qkv." in name:
+            c = p.shape[0] // 3
+            g, gref, gac = g[2 * c:], gref[2 * c:], gac[2 * c:]
+        e_h, e_a = rel_l2(g, gref), rel_l2(gac, gref)
+        worst = max(worst, e_h / (2 * e_a + 2e-2))
+        assert e_h <= 2 * e_a + 2e-2, (name, e_h, e_a)
+    print(f"worst ratio err_hip / (2 err_autocast + 2e-2) = {worst:.2f}")

@@ -19,7 +19,7 @@ __device__ __forceinline__ void unpack8a(const uint4 v, float* f) {
     f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
 
-#define ATTN_POS_PER_BLOCK_ROUNDS 4
+#define ATTN_POS_PER_BLOCK_ROUNDS 1   // more, smaller blocks: 4 rounds left half of the CUs idle at 64x64 positions
 
 // grid: (tiles, n); block 256.  Each thread owns one 8-channel chunk of `rounds` positions.
 __global__ void __launch_bounds__(256)
@@ -44,9 +44,26 @@ attn_depthsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ depthsum,
 #pragma unroll
             for (int k = 0; k < 8; ++k) s[k] = 0.0f;
             const bf16_t* base = x + (((long long)nb * d) * hw + pos) * c + q * 8;
-            for (int dd = 0; dd < d; ++dd) {
+            const long long dstride = (long long)hw * c;
+            int dd = 0;
+            for (; dd + 4 <= d; dd += 4) {     // four depth slices in flight per thread
+                uint4 raw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(base + (dd + u) * dstride);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[8];
+                    unpack8a(raw[u], f);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        s[k] += f[k];
+                        c2[k] += f[k] * f[k];
+                    }
+                }
+            }
+            for (; dd < d; ++dd) {
                 float f[8];
-                unpack8a(*reinterpret_cast<const uint4*>(base + (long long)dd * hw * c), f);
+                unpack8a(*reinterpret_cast<const uint4*>(base + dd * dstride), f);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     s[k] += f[k];

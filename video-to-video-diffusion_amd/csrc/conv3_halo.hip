@@ -21,26 +21,38 @@
 #include "conv3_halo_common.h"
 #include <string.h>
 
-namespace h3 {
-constexpr int TD = 4, TH = 4, TW = 16;
-constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
-constexpr int HV = HD * HH * HW;               // 648 halo voxels
-constexpr int HALO_INSTR = (HV + 15) / 16;     // 41 DMA wave-instructions of 16 voxels x 64 B
-constexpr int HALO_BYTES = HALO_INSTR * 1024;  // 41984
-constexpr int BM = TD * TH * TW;               // 256
-constexpr int BN = 128;
-constexpr int WSLOT_BYTES = 3 * BN * 64;       // 3 taps x 128 couts x 32 ch bf16
-constexpr int NW = 8, NTH = 512;
-constexpr int OFF_W = 2 * HALO_BYTES;
-constexpr int OFF_ROW = OFF_W + 2 * WSLOT_BYTES;
-constexpr int OFF_CS = OFF_ROW + BM * 8;
-constexpr int LDS_BYTES = OFF_CS + 4 * BN * 8;  // column-sum scratch [4][BN][2] floats
-}  // namespace h3
+// Tile shapes: <4,4> = 4 x 4 x 16 voxels (8 waves) and <6,2> = 6 x 2 x 16 voxels (6 waves; 48 x 16 x 16 volumes split
+// into exactly 64 tiles -> 256 blocks with 4 cout tiles: one per CU instead of 192 blocks on 256 CUs).
+template <int TD_, int TH_>
+struct H3Cfg {
+    static constexpr int TD = TD_, TH = TH_, TW = 16;
+    static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+    static constexpr int HV = HD * HH * HW;               // <4,4>: 648 halo voxels
+    static constexpr int HALO_INSTR = (HV + 15) / 16;     // <4,4>: 41 DMA wave-instructions of 16 voxels x 64 B
+    static constexpr int HALO_BYTES = HALO_INSTR * 1024;
+    static constexpr int BM = TD * TH * TW;               // 256 / 192
+    static constexpr int BN = 128;
+    static constexpr int WM = BM / 64;                    // M-waves (64 voxels = 4 W-lines each)
+    static constexpr int NW = 2 * WM, NTH = 64 * NW;
+    static constexpr int NPIECE = (HALO_INSTR + NW - 1) / NW;   // halo DMAs per wave and chunk (<= 6: issued at g < 6)
+    static constexpr int WPIECE = 24 / NW;                // 1 KB weight pieces per wave and step (3 taps x 8 KB)
+    static constexpr int WSLOT_BYTES = 3 * BN * 64;       // 3 taps x 128 couts x 32 ch bf16
+    static constexpr int OFF_W = 2 * HALO_BYTES;
+    static constexpr int OFF_ROW = OFF_W + 2 * WSLOT_BYTES;
+    static constexpr int OFF_CS = OFF_ROW + BM * 8;
+    static constexpr int LDS_BYTES = OFF_CS + WM * BN * 8;  // column-sum scratch [WM][BN][2] floats
+    static_assert(BM % 64 == 0 && 24 % NW == 0 && NPIECE <= 6, "unsupported tile");
+};
 
-__global__ void __launch_bounds__(512)
+template <int TD_, int TH_>
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, H3Cfg<TD_, TH_>::NTH)))
 conv3_halo_kernel(const Conv3HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using namespace h3;
+    using Cfg = H3Cfg<TD_, TH_>;
+    constexpr int TD = Cfg::TD, TH = Cfg::TH, TW = Cfg::TW, HH = Cfg::HH, HW = Cfg::HW, HV = Cfg::HV;
+    constexpr int HALO_INSTR = Cfg::HALO_INSTR, HALO_BYTES = Cfg::HALO_BYTES, BM = Cfg::BM, BN = Cfg::BN;
+    constexpr int WM = Cfg::WM, NW = Cfg::NW, NTH = Cfg::NTH, NPIECE = Cfg::NPIECE, WPIECE = Cfg::WPIECE;
+    constexpr int WSLOT_BYTES = Cfg::WSLOT_BYTES, OFF_W = Cfg::OFF_W, OFF_ROW = Cfg::OFF_ROW, OFF_CS = Cfg::OFF_CS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long* s_rowoff = reinterpret_cast<long long*>(smem + OFF_ROW);
     float* s_cs = reinterpret_cast<float*>(smem + OFF_CS);
@@ -86,12 +98,12 @@ conv3_halo_kernel(const Conv3HaloParams p) {
     const v4i_t rsw = h3_make_rsrc(wb, 0x7fffffffu);
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;   // LDS byte address of the dynamic region
 
-    // this wave issues halo instructions j = wave + 8*i (i < 6, j < 41); lane -> voxel 16j + (lane>>2)
+    // this wave issues halo instructions j = wave + NW*i (i < NPIECE, j < HALO_INSTR); lane -> voxel 16j + (lane>>2)
     const int hq = (lane & 3) ^ (lane >> 4);  // logical 8-channel chunk landing in this lane's 16-B slot
-    int hrel[6];                               // voxel index relative to basevox, or -1
+    int hrel[NPIECE];                          // voxel index relative to basevox, or -1
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int j = wave + 8 * i;
+    for (int i = 0; i < NPIECE; ++i) {
+        const int j = wave + NW * i;
         const int v = j * 16 + (lane >> 2);
         const int hd = v / (HH * HW), rem = v - hd * (HH * HW);
         const int hh = rem / HW, hw = rem - hh * HW;
@@ -100,12 +112,12 @@ conv3_halo_kernel(const Conv3HaloParams p) {
                         gw < p.Wi;
         hrel[i] = ok ? ((gd - dlo) * p.Hi + gh) * p.Wi + gw : -1;
     }
-    const unsigned w_voff = (unsigned)wave * 1024u + (unsigned)lane * 16u;
+    const unsigned w_voff = (unsigned)lane * 16u;
     const int C1 = p.C1, C2 = p.C2, CoutPad = p.CoutPad, nchunks = p.nchunks;
 
     // `hoff`/`woff`: byte offset of the destination buffer inside the dynamic LDS region
     auto issue_halo = [&](int cc, int i, int hoff) {  // one DMA instruction (16 voxels) of chunk cc
-        const int j = wave + 8 * i;
+        const int j = wave + NW * i;
         if (j >= HALO_INSTR) return;
         const int ch0 = cc * 32;
         const bool second = ch0 >= C1;
@@ -113,7 +125,7 @@ conv3_halo_kernel(const Conv3HaloParams p) {
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? ch0 - C1 : ch0) * 2);
         int hsel = hrel[0];
 #pragma unroll
-        for (int q = 1; q < 6; ++q) hsel = (i == q) ? hrel[q] : hsel;
+        for (int q = 1; q < NPIECE; ++q) hsel = (i == q) ? hrel[q] : hsel;
         const unsigned voff = hsel >= 0 ? (unsigned)hsel * cbytes + (unsigned)hq * 16u : 0x80000000u;
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + hoff + j * 1024));
         if (second)
@@ -121,12 +133,14 @@ conv3_halo_kernel(const Conv3HaloParams p) {
         else
             h3_dma16(rs1, dst, voff, soff);
     };
-    auto issue_weights = [&](int s, int woff) {  // the 3 taps of step s: wave loads rows 16w..16w+15 of each
+    auto issue_weights = [&](int s, int woff) {  // the 3 taps of step s = 24 pieces of 1 KB (16 cout rows): WPIECE per wave
         const int cc = s / 9, g = s - cc * 9;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((cc * 27 + g * 3 + i) * CoutPad) * 64);
-            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + woff + i * (BN * 64) + wave * 1024));
+        for (int i = 0; i < WPIECE; ++i) {
+            const int piece = wave * WPIECE + i;
+            const int tap = piece >> 3, sub = piece & 7;
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((cc * 27 + g * 3 + tap) * CoutPad) * 64 + sub * 1024);
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + woff + tap * (BN * 64) + sub * 1024));
             h3_dma16(rsw, dst, w_voff, soff);
         }
     };
@@ -134,7 +148,12 @@ conv3_halo_kernel(const Conv3HaloParams p) {
     // ---- fragment addressing -----------------------------------------------------------------------------------
     const int kg = lane >> 4, m = lane & 15;
     const int half0 = (kg & 1) * 8;
-    const int va = (wm * HH) * HW + m;                    // halo voxel of (ld = wm, lh = 0, kw = 0) before taps
+    int vline[4];                                         // halo voxel of this wave's 4 W-lines (line = 4*wm + i) before taps
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int line = wm * 4 + i;
+        vline[i] = ((line / TH) * HH + (line % TH)) * HW + m;
+    }
     const int rowb = wn * 64 + m;                          // weight row of n-tile 0 of this wave
     const int b_off = rowb * 64 + ((kg ^ ((rowb >> 2) & 3)) << 4) + half0;   // + j*1024 + kw*BN*64
 
@@ -165,7 +184,7 @@ conv3_halo_kernel(const Conv3HaloParams p) {
 #define H3_LOAD(FA, FB, HBUF, WBUF, VS, KW)                                                                    \
     {                                                                                                          \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
-            const int v_ = (VS) + i_ * HW + (KW);                                                              \
+            const int v_ = (VS) + vline[i_] + (KW);                                                            \
             const char* a_ = (HBUF) + v_ * 64 + ((kg ^ ((v_ >> 2) & 3)) << 4);                                 \
             const uint2 lo_ = *reinterpret_cast<const uint2*>(a_ + half0);                                     \
             const uint2 hi_ = *reinterpret_cast<const uint2*>(a_ + (half0 ^ 8));                               \
@@ -190,19 +209,19 @@ conv3_halo_kernel(const Conv3HaloParams p) {
 
     // prologue: halo of chunk 0, weights of steps 0 and 1
 #pragma unroll
-    for (int i = 0; i < 6; ++i) issue_halo(0, i, 0);
+    for (int i = 0; i < NPIECE; ++i) issue_halo(0, i, 0);
     issue_weights(0, OFF_W);
     if (S > 1) issue_weights(1, OFF_W + WSLOT_BYTES);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    H3_LOAD(fa0, fb0, smem, smem + OFF_W + b_off, va, 0);
+    H3_LOAD(fa0, fb0, smem, smem + OFF_W + b_off, 0, 0);
 
     int cc = 0, g = 0;
     for (int s = 0; s < S; ++s) {
         const char* hbuf = smem + (cc & 1) * HALO_BYTES;
         const char* wbuf = smem + OFF_W + (s & 1) * WSLOT_BYTES + b_off;
         const int kd = g / 3, kh = g - kd * 3;
-        const int vs = va + (kd * HH + kh) * HW;
+        const int vs = (kd * HH + kh) * HW;
         H3_LOAD(fa1, fb1, hbuf, wbuf, vs, 1);
         __builtin_amdgcn_sched_barrier(0);
         H3_MFMA(fa0, fb0);
@@ -216,7 +235,7 @@ conv3_halo_kernel(const Conv3HaloParams p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < S) issue_weights(s + 2, OFF_W + (s & 1) * WSLOT_BYTES);
-        if (g < 6 && cc + 1 < nchunks) issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
+        if (g < NPIECE && cc + 1 < nchunks) issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
         int g2 = g + 1, cc2 = cc;
         if (g2 == 9) {
             g2 = 0;
@@ -225,7 +244,7 @@ conv3_halo_kernel(const Conv3HaloParams p) {
         if (s + 1 < S) {
             const int kd2 = g2 / 3, kh2 = g2 - kd2 * 3;
             H3_LOAD(fa0, fb0, smem + (cc2 & 1) * HALO_BYTES, smem + OFF_W + ((s + 1) & 1) * WSLOT_BYTES + b_off,
-                    va + (kd2 * HH + kh2) * HW, 0);
+                    (kd2 * HH + kh2) * HW, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         H3_MFMA(fa2, fb2);
@@ -282,7 +301,7 @@ conv3_halo_kernel(const Conv3HaloParams p) {
     if (want_sums && tid < BN) {
         float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < WM; ++q) {
             t1 += s_cs[(q * BN + tid) * 2 + 0];
             t2 += s_cs[(q * BN + tid) * 2 + 1];
         }
@@ -625,17 +644,28 @@ extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int 
 extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void* stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)h3::LDS_BYTES);
+        using C44 = H3Cfg<4, 4>;
+        using C62 = H3Cfg<6, 2>;
+        auto k44 = conv3_halo_kernel<4, 4>;
+        auto k62 = conv3_halo_kernel<6, 2>;
+        hipFuncSetAttribute((const void*)k44, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C44::LDS_BYTES);
+        hipFuncSetAttribute((const void*)k62, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C62::LDS_BYTES);
         hipFuncSetAttribute((const void*)conv3_halo32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h32::LDS_BYTES);
         attr_done = true;
     }
     const int grid = hp->mtiles * hp->ntiles_n;
-    if (wide)
+    if (wide == 1)
         hipLaunchKernelGGL(conv3_halo32_kernel, dim3(grid), dim3(512), h32::LDS_BYTES, (hipStream_t)stream, *hp);
-    else
-        hipLaunchKernelGGL(conv3_halo_kernel, dim3(grid), dim3(512), h3::LDS_BYTES, (hipStream_t)stream, *hp);
+    else if (wide == 2) {
+        using C62 = H3Cfg<6, 2>;
+        auto k62 = conv3_halo_kernel<6, 2>;
+        hipLaunchKernelGGL(k62, dim3(grid), dim3(C62::NTH), C62::LDS_BYTES, (hipStream_t)stream, *hp);
+    } else {
+        using C44 = H3Cfg<4, 4>;
+        auto k44 = conv3_halo_kernel<4, 4>;
+        hipLaunchKernelGGL(k44, dim3(grid), dim3(C44::NTH), C44::LDS_BYTES, (hipStream_t)stream, *hp);
+    }
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

@@ -479,6 +479,7 @@ struct ctsi_conv_plan {
     int8_t pH[4], pW[4];
     int tap_margin[4], ad_min[4];
     int fast, dshift;
+    int halo16_62;  // halo3 == 1 only: 6x2x16 tile instead of 4x4x16
     int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip);
                 // 3: 4x2x32 tile, persistent blocks (conv3_halo_persist.hip)
     double flops;
@@ -689,6 +690,15 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
         p->TD = 4; p->TH = 2; p->TW = 32;
     } else if (p->halo3) {
         p->TD = 4; p->TH = 4; p->TW = 16;
+        // 6 x 2 x 16 tile (6 waves, conv3_halo_kernel<6,2>): turns the 192 blocks of a 48 x 16 x 16 / 512-cout layer into
+        // exactly 256, but measured SLOWER (734 vs 826 TFLOP/s): each block still streams the full 27 x 8 KB weight slab per
+        // chunk for 25 % fewer voxels, and the weight fill, not the idle quarter of the CUs, bounds these layers.  Opt-in.
+        const char* t62 = getenv("CTSI_CONV_HALO16_TILE");   // "62" (tuning aid)
+        if (t62 && !strcmp(t62, "62")) {
+            p->TD = 6; p->TH = 2;
+            p->BM = 192;
+            p->halo16_62 = 1;
+        }
     } else {
         choose_tile(p->BM, p->Dr, p->Hr, p->Wr, &p->TD, &p->TH, &p->TW);
     }
@@ -859,7 +869,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             const char* nb_env = getenv("CTSI_CONV_PERSIST_BLOCKS");   // test aid: force tile switching
             return ctsi_conv3_halo_persist_launch(&h, nb_env ? atoi(nb_env) : ncu, stream);
         }
-        return ctsi_conv3_halo_launch(&h, p->halo3 == 2, stream);
+        return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? 1 : (p->halo16_62 ? 2 : 0), stream);
     }
     CTSI_CHECK_ARG(!p->halo3, "ctsi_conv_fwd: the 3x3x3 halo-tile plan supports bf16 NDHWC output without activation");
     ConvKParams k;

@@ -95,7 +95,7 @@ def test_conv_plan_errors_are_reported_not_raised_in_c(lib):
 def test_tile_counts_host_helpers(lib):
     assert lib.gn_colsum_tiles(48, 128, 128) == 48 * 128 * 128 // 512
     assert lib.gn_colsum_tiles(1, 3, 5) == 1
-    assert lib.attn_depthsum_tiles(256, 64, 64) == 64 * 64 // (8 * 4)
+    assert lib.attn_depthsum_tiles(256, 64, 64) == 64 * 64 // 8      # 256/(c/8) = 8 positions per block, one round
     assert lib.attn_depthsum_tiles(7, 4, 4) == 0
 
 

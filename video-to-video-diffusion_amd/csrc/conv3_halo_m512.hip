@@ -1,0 +1,341 @@
+// 3x3x3 stride-1 convolution, LDS halo tile 4 x 4 x 32 voxels (512 output voxels) x 128 couts, 16-channel chunks.
+//
+// Measured on conv3_halo32_kernel (4x2x32 x 128 couts, 32-channel chunks): the LDS-DMA *instructions* (1 KB per wave
+// instruction, ~100+ issue cycles each inside an MFMA phase) cost 11-15 % of the kernel, most of them weight pieces
+// (27 x 8 KB per chunk and block).  Doubling the voxel tile halves the weight pieces per MFMA; 16-channel chunks
+// (32-byte halo rows) keep the double-buffered halo at 2 x 39 KB.  Per wave: 64 voxels (2 W-lines) x 128 couts =
+// 2 x 4 MFMA tiles of 32x32 (128 accumulators), 6 ds_read_b128 per 8 MFMAs; DMA instructions per MFMA: 0.085 instead
+// of 0.155; LDS fill 385 flop/B instead of 211; prologue / epilogue amortised over twice the work.
+// Weight image and swizzles as in conv3_halo_n64.hip ([chunk16][27][cout_pad][16], slot = khalf ^ ((row >> 3) & 1)),
+// 4-deep weight ring with counted vmcnt waits.  The 128 KB output tile goes through LDS in two halves.
+#include "conv3_halo_common.h"
+#include <stdlib.h>
+
+namespace hm {
+constexpr int TD = 4, TH = 4, TW = 32;
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+constexpr int HV = HD * HH * HW;                 // 1224 halo voxels
+constexpr int HALO_INSTR = (HV + 31) / 32;       // 39 wave-DMAs of 32 voxels x 32 B
+constexpr int HALO_BYTES = HALO_INSTR * 1024;    // 39936
+constexpr int BM = TD * TH * TW;                 // 512
+constexpr int BN = 128;
+constexpr int TAP_BYTES = BN * 32;               // 4096
+constexpr int WSLOT_BYTES = 3 * TAP_BYTES;       // 12288
+constexpr int NWS = 4;
+constexpr int NTH = 512;
+constexpr int NWAVE = 8;
+constexpr int NPIECE = (HALO_INSTR + NWAVE - 1) / NWAVE;   // 5 halo DMAs per wave and chunk
+constexpr int OFF_W = 2 * HALO_BYTES;            // 79872
+constexpr int OFF_ROW = OFF_W + NWS * WSLOT_BYTES;   // 129024
+constexpr int LDS_BYTES = OFF_ROW + BM * 8;      // 133120
+constexpr int OFF_CS = (BM / 2) * BN * 2;        // epilogue only: column-sum scratch behind the 64 KB half tile
+}  // namespace hm
+
+__device__ __forceinline__ void hm_wait_vm(int allowed) {   // wave-uniform `allowed`
+    switch (allowed) {
+        case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+    }
+}
+
+__global__ void __launch_bounds__(512)
+conv3_halo32m_kernel(const Conv3HaloParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace hm;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long* s_rowoff = reinterpret_cast<long long*>(smem + OFF_ROW);
+    float* s_cs = reinterpret_cast<float*>(smem + OFF_CS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // lines 2*wave, 2*wave+1 of the tile (line = ld*TH + lh)
+    const int wm = wave;
+
+    const int bid = xcd_remap_h(blockIdx.x, gridDim.x);
+    const int mt = bid / p.ntiles_n;
+    const int nt = bid - mt * p.ntiles_n;
+    const int n0 = nt * BN;
+    const int nb = mt / p.tps;
+    int r0 = mt - nb * p.tps;
+    const int tD = r0 / (p.tilesH * p.tilesW);
+    r0 -= tD * p.tilesH * p.tilesW;
+    const int tH = r0 / p.tilesW;
+    const int tW = r0 - tH * p.tilesW;
+    const int d0 = tD * TD, h0 = tH * TH, w0 = tW * TW;
+
+    {   // row = line*32 + m, line = ld*TH + lh
+        const int mm = tid & 31, line = tid >> 5;
+        const int d = d0 + line / TH, h = h0 + line % TH, w = w0 + mm;
+        long long off = -1;
+        if (d < p.Do && h < p.Ho && w < p.Wo)
+            off = ((((long long)nb * p.Do + d) * p.Ho + h) * p.Wo + w) * p.cout_stride + p.c_off;
+        s_rowoff[tid] = off;
+    }
+
+    int dlo = d0 + p.dshift - 1;
+    dlo = dlo < 0 ? 0 : dlo;
+    const long long basevox = ((long long)(nb * p.Di + dlo) * p.Hi) * p.Wi;
+    const v4i_t rs1 = h3_make_rsrc(reinterpret_cast<const char*>(p.x1) + basevox * p.C1 * 2, 0x7fffffffu);
+    const v4i_t rs2 = h3_make_rsrc(reinterpret_cast<const char*>(p.x2) + basevox * p.C2 * 2, 0x7fffffffu);
+    const v4i_t rsw = h3_make_rsrc(reinterpret_cast<const char*>(p.w) + (long long)n0 * 32, 0x7fffffffu);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;
+
+    // halo DMA: piece j = wave + NWAVE*i covers halo voxels 32*j .. 32*j+31; lane -> voxel 32*j + lane/2, physical slot lane&1
+    int hrel[NPIECE];
+    unsigned hq16[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int j = wave + NWAVE * i;
+        const int v = j * 32 + (lane >> 1);
+        const int hd = v / (HH * HW), rem = v - hd * (HH * HW);
+        const int hh = rem / HW, hw = rem - hh * HW;
+        const int gd = d0 + p.dshift - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+        const bool ok = (j < HALO_INSTR) && (v < HV) && gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 &&
+                        gw < p.Wi;
+        hrel[i] = ok ? ((gd - dlo) * p.Hi + gh) * p.Wi + gw : -1;
+        hq16[i] = (unsigned)(((lane & 1) ^ ((v >> 3) & 1)) * 16);   // logical 8-channel half stored in this slot
+    }
+    const int C1 = p.C1, C2 = p.C2, CoutPad = p.CoutPad, nchunks = p.nchunks;
+
+    auto issue_halo = [&](int cc, int i, int hoff) -> int {
+        const int j = wave + NWAVE * i;
+        if (j >= HALO_INSTR) return 0;
+        const int ch0 = cc * 16;
+        const bool second = ch0 >= C1;
+        const unsigned cbytes = (unsigned)((second ? C2 : C1) * 2);
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? ch0 - C1 : ch0) * 2);
+        int hsel = hrel[0];
+        unsigned qsel = hq16[0];
+#pragma unroll
+        for (int q = 1; q < NPIECE; ++q) {
+            hsel = (i == q) ? hrel[q] : hsel;
+            qsel = (i == q) ? hq16[q] : qsel;
+        }
+        const unsigned voff = hsel >= 0 ? (unsigned)hsel * cbytes + qsel : 0x80000000u;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + hoff + j * 1024));
+        if (second)
+            h3_dma16(rs2, dst, voff, soff);
+        else
+            h3_dma16(rs1, dst, voff, soff);
+        return 1;
+    };
+    // weights of step s = 3 taps x 4 KB = 12 pieces of 1 KB: wave w copies piece w, waves 0..3 also piece 8 + w
+    const unsigned w_voff = (unsigned)lane * 16u;
+    auto issue_weights = [&](int s) -> int {
+        const int cc = s / 9, g = s - cc * 9;
+        const unsigned slot = lds0 + OFF_W + (s & (NWS - 1)) * WSLOT_BYTES;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int piece = wave + NWAVE * k;
+            if (piece < 12) {
+                const int tap = piece >> 2, quarter = piece & 3;
+                const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(
+                    ((cc * 27 + g * 3 + tap) * CoutPad) * 32 + quarter * 1024);
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(slot + piece * 1024));
+                h3_dma16(rsw, dst, w_voff, soff);
+                ++cnt;
+            }
+        }
+        return cnt;
+    };
+
+    // fragment addressing: lane -> row r = lane & 31 of the 32-row operand tile, k-half hk = lane >> 5
+    const int hk = lane >> 5, r = lane & 31;
+    int vline[2];                                            // halo voxel of this wave's two W-lines before taps
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int line = 2 * wm + i;
+        vline[i] = ((line / TH) * HH + (line % TH)) * HW + r;
+    }
+    const int b_off = r * 32 + ((hk ^ ((r >> 3) & 1)) << 4);    // n-tile j: + j*1024 (rows +32 keep (row>>3)&1)
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+
+    bf16x8 fa0[2], fb0[4], fa1[2], fb1[4], fa2[2], fb2[4];
+    const int S = nchunks * 9;
+
+#define HN_LOAD(FA, FB, HBUF, WBUF, VS, KW)                                                                    \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
+            const int v_ = (VS) + vline[i_] + (KW);                                                            \
+            FA[i_] = *reinterpret_cast<const bf16x8*>((HBUF) + v_ * 32 + ((hk ^ ((v_ >> 3) & 1)) << 4));       \
+        }                                                                                                      \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                       \
+            FB[j_] = *reinterpret_cast<const bf16x8*>((WBUF) + b_off + (KW) * TAP_BYTES + j_ * 1024);          \
+    }
+    // one phase = the MFMAs of one tap (set c) interleaved with the fragment loads of the tap two phases ahead (set l)
+#define HN_PHASE(FAc, FBc, FAl, FBl, HBUF, WBUF, VS, KW)                                                       \
+    {                                                                                                          \
+        HN_LOAD(FAl, FBl, HBUF, WBUF, VS, KW);                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)       \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FAc[i_], FBc[j_], acc[i_][j_], 0, 0, 0);     \
+        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+
+    // prologue: halo of chunk 0, weights of steps 0..3
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) issue_halo(0, i, 0);
+    int n_prev1 = 0, n_prev2 = 0;   // DMAs this wave issued in the previous step / the one before (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < NWS; ++s)
+        if (s < S) issue_weights(s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    HN_LOAD(fa0, fb0, smem, smem + OFF_W, 0, 0);
+    HN_LOAD(fa1, fb1, smem, smem + OFF_W, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    int cc = 0, g = 0;
+    for (int s = 0; s < S; ++s) {
+        const char* hbuf = smem + (cc & 1) * HALO_BYTES;
+        const char* wbuf = smem + OFF_W + (s & (NWS - 1)) * WSLOT_BYTES;
+        const int kd = g / 3, kh = g - kd * 3;
+        const int vs = (kd * HH + kh) * HW;
+        HN_PHASE(fa0, fb0, fa2, fb2, hbuf, wbuf, vs, 2);
+        // slot s is drained by this wave once the loads above have returned.  Needed next: weights of step s+1 (issued 3
+        // steps ago); the next chunk's halo pieces are issued at g = 0..4, so they are older than the two most recent
+        // steps' DMAs by the time they are read (g = 8).
+        hm_wait_vm(n_prev1 + n_prev2);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        int issued = 0;
+        if (s + NWS < S && !(p.dbg & 2)) issued += issue_weights(s + NWS);
+        if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1)) issued += issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
+        n_prev2 = n_prev1;
+        n_prev1 = issued;
+        int g2 = g + 1, cc2 = cc;
+        if (g2 == 9) {
+            g2 = 0;
+            ++cc2;
+        }
+        // (the last step's look-ahead loads read stale but in-bounds LDS and are never consumed)
+        const char* hbuf2 = smem + (cc2 & 1) * HALO_BYTES;
+        const char* wbuf2 = smem + OFF_W + ((s + 1) & (NWS - 1)) * WSLOT_BYTES;
+        const int kd2 = g2 / 3, kh2 = g2 - kd2 * 3;
+        const int vs2 = (kd2 * HH + kh2) * HW;
+        __builtin_amdgcn_sched_barrier(0);
+        HN_PHASE(fa1, fb1, fa0, fb0, hbuf2, wbuf2, vs2, 0);
+        HN_PHASE(fa2, fb2, fa1, fb1, hbuf2, wbuf2, vs2, 1);
+        g = g2;
+        cc = cc2;
+    }
+#undef HN_PHASE
+#undef HN_LOAD
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- epilogue: bias, GroupNorm column sums, bf16 tile through LDS in two halves of 256 rows (64 KB each) ---------
+    if (p.dbg & 8) return;
+    bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [256][BN] bf16
+    const bool want_sums = p.colsum != nullptr;
+    const int lhi = lane >> 5, lcol = lane & 31;
+    unsigned vbits[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        unsigned vb = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhi;
+            vb |= (unsigned)(s_rowoff[row] >= 0) << q;
+        }
+        vbits[i] = vb;
+    }
+    float cs1[4], cs2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs1[j] = cs2[j] = 0.0f;
+    for (int half = 0; half < 2; ++half) {
+        if ((wm >> 2) == half) {
+            const int wl = wm & 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = j * 32 + lcol;
+                const int co = n0 + col;
+                const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    bf16_t* trow = s_tile + ((wl * 2 + i) * 32 + 4 * lhi) * BN + col;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float v = acc[i][j][q] + bv;
+                        trow[((q & 3) + 8 * (q >> 2)) * BN] = f32_to_bf16(v);
+                        if (want_sums) {
+                            const float vm = ((vbits[i] >> q) & 1u) ? v : 0.0f;
+                            cs1[j] += vm;
+                            cs2[j] += vm * vm;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            constexpr int CPR = BN / 8;
+            bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+            for (int c = tid; c < 256 * CPR; c += NTH) {
+                const int row = c / CPR, ch = c - row * CPR;
+                const long long off = s_rowoff[half * 256 + row];
+                const int co = n0 + ch * 8;
+                if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
+                    *reinterpret_cast<uint4*>(y + off + co) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (want_sums) {   // [8 waves][BN][2] partials -> one row per m-tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s1 = cs1[j] + __shfl_xor(cs1[j], 32);
+            float s2 = cs2[j] + __shfl_xor(cs2[j], 32);
+            if (lhi == 0) {
+                s_cs[(wm * BN + j * 32 + lcol) * 2 + 0] = s1;
+                s_cs[(wm * BN + j * 32 + lcol) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < NWAVE; ++q) {
+                t1 += s_cs[(q * BN + tid) * 2 + 0];
+                t2 += s_cs[(q * BN + tid) * 2 + 1];
+            }
+            const long long slab = (long long)p.mtiles * CoutPad;
+            p.colsum[(long long)mt * CoutPad + n0 + tid] = t1;
+            p.colsum[slab + (long long)mt * CoutPad + n0 + tid] = t2;
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, void* stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv3_halo32m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)hm::LDS_BYTES);
+        attr_done = true;
+    }
+    const int grid = hp->mtiles * hp->ntiles_n;
+    hipLaunchKernelGGL(conv3_halo32m_kernel, dim3(grid), dim3(hm::NTH), hm::LDS_BYTES, (hipStream_t)stream, *hp);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}

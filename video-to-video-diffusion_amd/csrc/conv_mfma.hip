@@ -682,11 +682,27 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 p->halo3 = 4;
                 p->BN = 64;
             }
+            // 512-voxel tile (4 x 4 x 32) x 128 couts, 16-channel chunks: half the weight DMA pieces per MFMA (conv3_halo_m512.hip)
+            if (p->halo3 == 2) {
+                // used when the 512-voxel tiles still fill the 256 CUs evenly (>= 90 % of the last round) and do not add
+                // padding rows; e.g. 48x128x128 and 48x64x64 volumes yes, 48x32x32 with 512 couts (384 blocks) no
+                const long long t512 = (long long)d.n * ceil_div(p->Dr, 4) * ceil_div(p->Hr, 4) * ceil_div(p->Wr, 32);
+                const long long b512 = t512 * ceil_div(d.cout, 128);
+                const double fill = (double)b512 / (double)(((b512 + 255) / 256) * 256);
+                const char* m5 = getenv("CTSI_CONV_M512");   // "0" | "1" (tuning aid)
+                const bool want = (fill >= 0.9 && t512 * 512 <= padded32 * 11 / 10 * d.n) || (m5 && !strcmp(m5, "1"));
+                if (want && !(m5 && !strcmp(m5, "0"))) {
+                    p->halo3 = 5;
+                    p->BM = 512;
+                }
+            }
         }
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
-    if (p->halo3 >= 2) {
+    if (p->halo3 == 5) {
+        p->TD = 4; p->TH = 4; p->TW = 32;
+    } else if (p->halo3 >= 2) {
         p->TD = 4; p->TH = 2; p->TW = 32;
     } else if (p->halo3) {
         p->TD = 4; p->TH = 4; p->TW = 16;
@@ -764,7 +780,7 @@ extern "C" int ctsi_conv_plan_set_weight_cin(ctsi_conv_plan* p, int cin_w) {
 extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float* w, void* packed,
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
-    if (p->halo3 == 4) return ctsi_conv3_halo_n64_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
+    if (p->halo3 >= 4) return ctsi_conv3_halo_n64_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
     if (p->halo3) return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
     PackParams q;
     memset(&q, 0, sizeof(q));
@@ -847,7 +863,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         h.dshift = p->dshift;
         h.tilesD = p->tilesD; h.tilesH = p->tilesH; h.tilesW = p->tilesW; h.tps = p->tps; h.mtiles = p->mtiles;
         h.ntiles_n = p->ntiles_n;
-        h.nchunks = p->Cin / (p->halo3 == 4 ? 16 : 32);
+        h.nchunks = p->Cin / (p->halo3 >= 4 ? 16 : 32);
         h.Cout = p->d.cout; h.CoutPad = p->CoutPad;
         h.cout_stride = o->cout_stride; h.c_off = o->c_off;
         {
@@ -857,6 +873,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
         }
         if (p->halo3 == 4) return ctsi_conv3_halo_n64_launch(&h, stream);
+        if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, stream);
         if (p->halo3 == 3) {
             static int ncu = 0;
             if (!ncu) {

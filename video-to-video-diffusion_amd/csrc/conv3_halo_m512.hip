@@ -7,7 +7,8 @@
 // 2 x 4 MFMA tiles of 32x32 (128 accumulators), 6 ds_read_b128 per 8 MFMAs; DMA instructions per MFMA: 0.085 instead
 // of 0.155; LDS fill 385 flop/B instead of 211; prologue / epilogue amortised over twice the work.
 // Weight image and swizzles as in conv3_halo_n64.hip ([chunk16][27][cout_pad][16], slot = khalf ^ ((row >> 3) & 1)),
-// 4-deep weight ring with counted vmcnt waits.  The 128 KB output tile goes through LDS in two halves.
+// 4-deep weight ring with counted vmcnt waits.  The 128 KB output tile goes through LDS in one pass (it reuses the
+// halo + weight buffers; the row-offset table and the column-sum scratch sit behind it).
 #include "conv3_halo_common.h"
 #include <stdlib.h>
 
@@ -21,14 +22,16 @@ constexpr int BM = TD * TH * TW;                 // 512
 constexpr int BN = 128;
 constexpr int TAP_BYTES = BN * 32;               // 4096
 constexpr int WSLOT_BYTES = 3 * TAP_BYTES;       // 12288
-constexpr int NWS = 4;
+constexpr int NWS = 4;                           // weight ring: the DMA of step s+4 is issued when step s's slot is drained
+                                                 // (5 slots / 3 steps in flight measured 2-4 % slower)
 constexpr int NTH = 512;
 constexpr int NWAVE = 8;
 constexpr int NPIECE = (HALO_INSTR + NWAVE - 1) / NWAVE;   // 5 halo DMAs per wave and chunk
 constexpr int OFF_W = 2 * HALO_BYTES;            // 79872
-constexpr int OFF_ROW = OFF_W + NWS * WSLOT_BYTES;   // 129024
-constexpr int LDS_BYTES = OFF_ROW + BM * 8;      // 133120
-constexpr int OFF_CS = (BM / 2) * BN * 2;        // epilogue only: column-sum scratch behind the 64 KB half tile
+constexpr int OFF_ROW = OFF_W + NWS * WSLOT_BYTES;   // 141312: behind the main-loop buffers and the epilogue's 128 KB output tile
+constexpr int OFF_CS = OFF_ROW + BM * 8;         // 135168: column-sum scratch [8 waves][BN][2] floats
+constexpr int LDS_BYTES = OFF_CS + NWAVE * BN * 8;   // 143360
+static_assert(BM * BN * 2 <= OFF_ROW && LDS_BYTES <= 160 * 1024, "LDS layout");
 }  // namespace hm
 
 __device__ __forceinline__ void hm_wait_vm(int allowed) {   // wave-uniform `allowed`
@@ -39,7 +42,10 @@ __device__ __forceinline__ void hm_wait_vm(int allowed) {   // wave-uniform `all
         case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
     }
 }
 
@@ -128,7 +134,7 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     const unsigned w_voff = (unsigned)lane * 16u;
     auto issue_weights = [&](int s) -> int {
         const int cc = s / 9, g = s - cc * 9;
-        const unsigned slot = lds0 + OFF_W + (s & (NWS - 1)) * WSLOT_BYTES;
+        const unsigned slot = lds0 + OFF_W + (s % NWS) * WSLOT_BYTES;
         int cnt = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -193,7 +199,7 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     // prologue: halo of chunk 0, weights of steps 0..3
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) issue_halo(0, i, 0);
-    int n_prev1 = 0, n_prev2 = 0;   // DMAs this wave issued in the previous step / the one before (wave-uniform)
+    int n_prev1 = 0, n_prev2 = 0, n_prev3 = 0;   // DMAs this wave issued in each of the previous three steps (wave-uniform)
 #pragma unroll
     for (int s = 0; s < NWS; ++s)
         if (s < S) issue_weights(s);
@@ -206,19 +212,20 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     int cc = 0, g = 0;
     for (int s = 0; s < S; ++s) {
         const char* hbuf = smem + (cc & 1) * HALO_BYTES;
-        const char* wbuf = smem + OFF_W + (s & (NWS - 1)) * WSLOT_BYTES;
+        const char* wbuf = smem + OFF_W + (s % NWS) * WSLOT_BYTES;
         const int kd = g / 3, kh = g - kd * 3;
         const int vs = (kd * HH + kh) * HW;
         HN_PHASE(fa0, fb0, fa2, fb2, hbuf, wbuf, vs, 2);
-        // slot s is drained by this wave once the loads above have returned.  Needed next: weights of step s+1 (issued 3
-        // steps ago); the next chunk's halo pieces are issued at g = 0..4, so they are older than the two most recent
+        // slot s is drained by this wave once the loads above have returned.  Needed next: weights of step s+1 (issued NWS-1
+        // steps ago); the next chunk's halo pieces are issued at g = 0..4, so they are older than the NWS-2 most recent
         // steps' DMAs by the time they are read (g = 8).
-        hm_wait_vm(n_prev1 + n_prev2);
+        hm_wait_vm(n_prev1 + n_prev2 + (NWS > 4 ? n_prev3 : 0));
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         int issued = 0;
         if (s + NWS < S && !(p.dbg & 2)) issued += issue_weights(s + NWS);
         if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1)) issued += issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
+        n_prev3 = n_prev2;
         n_prev2 = n_prev1;
         n_prev1 = issued;
         int g2 = g + 1, cc2 = cc;
@@ -228,7 +235,7 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
         }
         // (the last step's look-ahead loads read stale but in-bounds LDS and are never consumed)
         const char* hbuf2 = smem + (cc2 & 1) * HALO_BYTES;
-        const char* wbuf2 = smem + OFF_W + ((s + 1) & (NWS - 1)) * WSLOT_BYTES;
+        const char* wbuf2 = smem + OFF_W + ((s + 1) % NWS) * WSLOT_BYTES;
         const int kd2 = g2 / 3, kh2 = g2 - kd2 * 3;
         const int vs2 = (kd2 * HH + kh2) * HW;
         __builtin_amdgcn_sched_barrier(0);
@@ -242,9 +249,9 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- epilogue: bias, GroupNorm column sums, bf16 tile through LDS in two halves of 256 rows (64 KB each) ---------
+    // ---- epilogue: bias, GroupNorm column sums, the 512 x 128 bf16 tile through LDS (128 KB), 16-byte row stores -----
     if (p.dbg & 8) return;
-    bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [256][BN] bf16
+    bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16
     const bool want_sums = p.colsum != nullptr;
     const int lhi = lane >> 5, lcol = lane & 31;
     unsigned vbits[2];
@@ -258,70 +265,58 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
         }
         vbits[i] = vb;
     }
-    float cs1[4], cs2[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cs1[j] = cs2[j] = 0.0f;
-    for (int half = 0; half < 2; ++half) {
-        if ((wm >> 2) == half) {
-            const int wl = wm & 3;
+    for (int j = 0; j < 4; ++j) {
+        const int col = j * 32 + lcol;
+        const int co = n0 + col;
+        const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
+        float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = j * 32 + lcol;
-                const int co = n0 + col;
-                const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
+        for (int i = 0; i < 2; ++i) {
+            bf16_t* trow = s_tile + ((wm * 2 + i) * 32 + 4 * lhi) * BN + col;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    bf16_t* trow = s_tile + ((wl * 2 + i) * 32 + 4 * lhi) * BN + col;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float v = acc[i][j][q] + bv;
-                        trow[((q & 3) + 8 * (q >> 2)) * BN] = f32_to_bf16(v);
-                        if (want_sums) {
-                            const float vm = ((vbits[i] >> q) & 1u) ? v : 0.0f;
-                            cs1[j] += vm;
-                            cs2[j] += vm * vm;
-                        }
-                    }
+            for (int q = 0; q < 16; ++q) {
+                const float v = acc[i][j][q] + bv;
+                trow[((q & 3) + 8 * (q >> 2)) * BN] = f32_to_bf16(v);
+                if (want_sums) {
+                    const float vm = ((vbits[i] >> q) & 1u) ? v : 0.0f;
+                    s1 += vm;
+                    s2 += vm * vm;
                 }
             }
         }
-        __syncthreads();
-        {
-            constexpr int CPR = BN / 8;
-            bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
-            for (int c = tid; c < 256 * CPR; c += NTH) {
-                const int row = c / CPR, ch = c - row * CPR;
-                const long long off = s_rowoff[half * 256 + row];
-                const int co = n0 + ch * 8;
-                if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
-                    *reinterpret_cast<uint4*>(y + off + co) = v;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (want_sums) {   // [8 waves][BN][2] partials -> one row per m-tile
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s1 = cs1[j] + __shfl_xor(cs1[j], 32);
-            float s2 = cs2[j] + __shfl_xor(cs2[j], 32);
+        if (want_sums) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
             if (lhi == 0) {
-                s_cs[(wm * BN + j * 32 + lcol) * 2 + 0] = s1;
-                s_cs[(wm * BN + j * 32 + lcol) * 2 + 1] = s2;
+                s_cs[(wm * BN + col) * 2 + 0] = s1;
+                s_cs[(wm * BN + col) * 2 + 1] = s2;
             }
         }
-        __syncthreads();
-        if (tid < BN) {
-            float t1 = 0.0f, t2 = 0.0f;
+    }
+    __syncthreads();
+    if (want_sums && tid < BN) {
+        float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
-            for (int q = 0; q < NWAVE; ++q) {
-                t1 += s_cs[(q * BN + tid) * 2 + 0];
-                t2 += s_cs[(q * BN + tid) * 2 + 1];
+        for (int q = 0; q < NWAVE; ++q) {
+            t1 += s_cs[(q * BN + tid) * 2 + 0];
+            t2 += s_cs[(q * BN + tid) * 2 + 1];
+        }
+        const long long slab = (long long)p.mtiles * CoutPad;
+        p.colsum[(long long)mt * CoutPad + n0 + tid] = t1;
+        p.colsum[slab + (long long)mt * CoutPad + n0 + tid] = t2;
+    }
+    {
+        constexpr int CPR = BN / 8;
+        bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+        for (int c = tid; c < BM * CPR; c += NTH) {
+            const int row = c / CPR, ch = c - row * CPR;
+            const long long off = s_rowoff[row];
+            const int co = n0 + ch * 8;
+            if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
+                const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
+                *reinterpret_cast<uint4*>(y + off + co) = v;
             }
-            const long long slab = (long long)p.mtiles * CoutPad;
-            p.colsum[(long long)mt * CoutPad + n0 + tid] = t1;
-            p.colsum[slab + (long long)mt * CoutPad + n0 + tid] = t2;
         }
     }
 #endif  // __HIP_DEVICE_COMPILE__

@@ -28,7 +28,8 @@ constexpr int NTH = 512;
 constexpr int NWAVE = 8;
 constexpr int NPIECE = (HALO_INSTR + NWAVE - 1) / NWAVE;   // 5 halo DMAs per wave and chunk
 constexpr int OFF_W = 2 * HALO_BYTES;            // 79872
-constexpr int OFF_ROW = OFF_W + NWS * WSLOT_BYTES;   // 141312: behind the main-loop buffers and the epilogue's 128 KB output tile
+constexpr int OFF_ROW = (OFF_W + NWS * WSLOT_BYTES > BM * BN * 2) ? OFF_W + NWS * WSLOT_BYTES : BM * BN * 2;   // 131072:
+                                                 // behind the main-loop buffers and the epilogue's 128 KB output tile
 constexpr int OFF_CS = OFF_ROW + BM * 8;         // 135168: column-sum scratch [8 waves][BN][2] floats
 constexpr int LDS_BYTES = OFF_CS + NWAVE * BN * 8;   // 143360
 static_assert(BM * BN * 2 <= OFF_ROW && LDS_BYTES <= 160 * 1024, "LDS layout");

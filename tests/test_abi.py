@@ -107,3 +107,32 @@ def test_tile_counts_host_helpers(lib):
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     with pytest.raises(L.CtsiError, match="no CPU fallback"):
         L._Lib(tmp_path / "libctsi.so")
+
+
+def test_training_and_next_row_entry_points_validate_arguments(lib):
+    """Argument checks run before any launch, so they are testable without a GPU: bad geometry comes back as a status
+    code with a message (CtsiError through the binding), never as a crash."""
+    ok = L.WgradDesc(3, 3, 3, 1, 1, 1, 1, 1, 4, 48, 48, 48, 48, 48, 48, 128, 128, 128, 128)
+    # config-3 L0 layer: 2 * voxels * 128 * 128 * 27 FLOP, split-K workspace is a multiple of the padded weight size
+    assert abs(lib.wgrad_flops(C.byref(ok)) - 2.0 * 4 * 48 ** 3 * 128 * 128 * 27) < 1
+    ws = lib.wgrad_workspace_bytes(C.byref(ok))
+    assert ws > 0 and ws % (27 * 128 * 128 * 4) == 0
+    bad = L.WgradDesc(3, 3, 3, 1, 1, 1, 1, 1, 1, 4, 4, 4, 4, 4, 4, 12, 12, 8, 8)     # 12 channels: not a multiple of 8
+    assert lib.wgrad_workspace_bytes(C.byref(bad)) == 0 and lib.wgrad_flops(C.byref(bad)) == 0.0
+    one = C.c_void_p(16)   # never dereferenced: every call below fails its argument check first
+    with pytest.raises(L.CtsiError, match="multiples of 8"):
+        lib.wgrad(C.byref(bad), one, one, one, one, 1, 1, 1, 1.0, None)
+    with pytest.raises(L.CtsiError, match="outside the volume"):
+        lib.blend_accumulate(one, one, one, one, one, one, 1, 4, 16, 16, 6, 24, 24, 3, 0, 0, None)
+    with pytest.raises(L.CtsiError, match="window must be odd"):
+        lib.slice_metrics(one, one, 1, 1, 2, 8, 8, 4, 1.0, one, one, None)
+    with pytest.raises(L.CtsiError, match="bad c="):
+        lib.gn_bwd(one, one, 0, one, one, one, 1, 12, 2, 2, 2, 5, 1e-5, 0, None, 0, None, one, one, one, one, one, None, 0,
+                   None, None)
+    with pytest.raises(L.CtsiError, match="bad arguments"):
+        lib.linear_bwd(one, one, one, 65, 8, 8, 0, one, one, one, None)      # more than 64 rows
+    with pytest.raises(L.CtsiError, match="bad arguments"):
+        lib.q_sample(one, one, one, one, one, one, 1, 8, 2, 2, 2, 8, 4, None)   # channel slice exceeds c_total
+    assert lib.gn_bwd_tiles(48, 48, 48) == 48 ** 3 // 512
+    assert lib.gn_bwd_workspace_floats(4, 128, 48, 48, 48, 8) == 4 * 216 * 4 * 128 + 4 * 8 * 2 + 4 * 4 * 128
+    assert lib.slice_metrics_workspace_doubles(1, 1, 48, 512, 512) == 48 * 32 * 32 * 4

@@ -35,4 +35,5 @@ for name, cin, cout, (d, h, w), kind in CASES:
         prof = prog.profile_ops(repeats=10)
     ms = [p for p in prof if p[2] > 0][0][3]
     fl = prog.conv_flops[0][1]
-    print(f"{name:14s} {fl/1e9:8.1f} GF  {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s")
+    kern = [p for p in prof if p[2] > 0][0][1]
+    print(f"{name:14s} {fl/1e9:8.1f} GF  {ms:7.3f} ms  {fl/ms/1e9:7.1f} TFLOP/s  {kern}")

@@ -12,28 +12,31 @@
 #include "conv3_halo_common.h"
 #include <stdlib.h>
 
-namespace hm {
-constexpr int TD = 4, TH = 4, TW = 32;
-constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
-constexpr int HV = HD * HH * HW;                 // 1224 halo voxels
-constexpr int HALO_INSTR = (HV + 31) / 32;       // 39 wave-DMAs of 32 voxels x 32 B
-constexpr int HALO_BYTES = HALO_INSTR * 1024;    // 39936
-constexpr int BM = TD * TH * TW;                 // 512
-constexpr int BN = 128;
-constexpr int TAP_BYTES = BN * 32;               // 4096
-constexpr int WSLOT_BYTES = 3 * TAP_BYTES;       // 12288
-constexpr int NWS = 4;                           // weight ring: the DMA of step s+4 is issued when step s's slot is drained
-                                                 // (5 slots / 3 steps in flight measured 2-4 % slower)
-constexpr int NTH = 512;
-constexpr int NWAVE = 8;
-constexpr int NPIECE = (HALO_INSTR + NWAVE - 1) / NWAVE;   // 5 halo DMAs per wave and chunk
-constexpr int OFF_W = 2 * HALO_BYTES;            // 79872
-constexpr int OFF_ROW = (OFF_W + NWS * WSLOT_BYTES > BM * BN * 2) ? OFF_W + NWS * WSLOT_BYTES : BM * BN * 2;   // 131072:
-                                                 // behind the main-loop buffers and the epilogue's 128 KB output tile
-constexpr int OFF_CS = OFF_ROW + BM * 8;         // 135168: column-sum scratch [8 waves][BN][2] floats
-constexpr int LDS_BYTES = OFF_CS + NWAVE * BN * 8;   // 143360
-static_assert(BM * BN * 2 <= OFF_ROW && LDS_BYTES <= 160 * 1024, "LDS layout");
-}  // namespace hm
+// Tile shapes: <4,4> = 4 x 4 x 32 = 512 voxels (8 waves) and <6,2> = 6 x 2 x 32 = 384 voxels (6 waves; a 48 x 32 x 32 level
+// with 512 couts gives 128 x 4 = 512 blocks = two full rounds on 256 CUs, where 512-voxel tiles give 384 blocks).
+template <int TD_, int TH_>
+struct HmCfg {
+    static constexpr int TD = TD_, TH = TH_, TW = 32;
+    static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+    static constexpr int HV = HD * HH * HW;                 // <4,4>: 1224 halo voxels
+    static constexpr int HALO_INSTR = (HV + 31) / 32;       // <4,4>: 39 wave-DMAs of 32 voxels x 32 B
+    static constexpr int HALO_BYTES = HALO_INSTR * 1024;
+    static constexpr int BM = TD * TH * TW;                 // 512 / 384
+    static constexpr int BN = 128;
+    static constexpr int TAP_BYTES = BN * 32;               // 4096
+    static constexpr int WSLOT_BYTES = 3 * TAP_BYTES;       // 12288
+    static constexpr int NWS = 4;                           // weight ring: the DMA of step s+4 is issued when step s's slot is
+                                                            // drained (5 slots / 3 steps in flight measured 2-4 % slower)
+    static constexpr int NWAVE = BM / 64;
+    static constexpr int NTH = 64 * NWAVE;                  // == BM: one output row per thread in the row table
+    static constexpr int NPIECE = (HALO_INSTR + NWAVE - 1) / NWAVE;   // halo DMAs per wave and chunk (issued at g < NPIECE)
+    static constexpr int OFF_W = 2 * HALO_BYTES;
+    static constexpr int LOOP_END = OFF_W + NWS * WSLOT_BYTES;
+    static constexpr int OFF_ROW = LOOP_END > BM * BN * 2 ? LOOP_END : BM * BN * 2;   // behind the loop buffers and the epilogue tile
+    static constexpr int OFF_CS = OFF_ROW + BM * 8;         // column-sum scratch [NWAVE][BN][2] floats
+    static constexpr int LDS_BYTES = OFF_CS + NWAVE * BN * 8;
+    static_assert(BM % 64 == 0 && NPIECE <= 6 && LDS_BYTES <= 160 * 1024, "unsupported tile");
+};
 
 __device__ __forceinline__ void hm_wait_vm(int allowed) {   // wave-uniform `allowed`
     switch (allowed) {
@@ -50,10 +53,16 @@ __device__ __forceinline__ void hm_wait_vm(int allowed) {   // wave-uniform `all
     }
 }
 
-__global__ void __launch_bounds__(512)
+template <int TD_, int TH_>
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, HmCfg<TD_, TH_>::NTH)))
 conv3_halo32m_kernel(const Conv3HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using namespace hm;
+    using Cfg = HmCfg<TD_, TH_>;
+    constexpr int TD = Cfg::TD, TH = Cfg::TH, TW = Cfg::TW, HH = Cfg::HH, HW = Cfg::HW, HV = Cfg::HV;
+    constexpr int HALO_INSTR = Cfg::HALO_INSTR, HALO_BYTES = Cfg::HALO_BYTES, BM = Cfg::BM, BN = Cfg::BN;
+    constexpr int TAP_BYTES = Cfg::TAP_BYTES, WSLOT_BYTES = Cfg::WSLOT_BYTES, NWS = Cfg::NWS, NWAVE = Cfg::NWAVE;
+    constexpr int NTH = Cfg::NTH, NPIECE = Cfg::NPIECE, OFF_W = Cfg::OFF_W, OFF_ROW = Cfg::OFF_ROW, OFF_CS = Cfg::OFF_CS;
+    static_assert(TD > 0, "");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long* s_rowoff = reinterpret_cast<long long*>(smem + OFF_ROW);
     float* s_cs = reinterpret_cast<float*>(smem + OFF_CS);
@@ -323,15 +332,22 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, void* stream) {
+extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile62, void* stream) {
+    using C44 = HmCfg<4, 4>;
+    using C62 = HmCfg<6, 2>;
+    auto k44 = conv3_halo32m_kernel<4, 4>;
+    auto k62 = conv3_halo32m_kernel<6, 2>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv3_halo32m_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)hm::LDS_BYTES);
+        hipFuncSetAttribute((const void*)k44, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C44::LDS_BYTES);
+        hipFuncSetAttribute((const void*)k62, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C62::LDS_BYTES);
         attr_done = true;
     }
     const int grid = hp->mtiles * hp->ntiles_n;
-    hipLaunchKernelGGL(conv3_halo32m_kernel, dim3(grid), dim3(hm::NTH), hm::LDS_BYTES, (hipStream_t)stream, *hp);
+    if (tile62)
+        hipLaunchKernelGGL(k62, dim3(grid), dim3(C62::NTH), C62::LDS_BYTES, (hipStream_t)stream, *hp);
+    else
+        hipLaunchKernelGGL(k44, dim3(grid), dim3(C44::NTH), C44::LDS_BYTES, (hipStream_t)stream, *hp);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

@@ -480,6 +480,7 @@ struct ctsi_conv_plan {
     int tap_margin[4], ad_min[4];
     int fast, dshift;
     int halo16_62;  // halo3 == 1 only: 6x2x16 tile instead of 4x4x16
+    int m512_62;    // halo3 == 5 only: 6x2x32 (384 voxels) tile instead of 4x4x32
     int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip);
                 // 3: 4x2x32 tile, persistent blocks (conv3_halo_persist.hip)
     double flops;
@@ -684,16 +685,30 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             }
             // 512-voxel tile (4 x 4 x 32) x 128 couts, 16-channel chunks: half the weight DMA pieces per MFMA (conv3_halo_m512.hip)
             if (p->halo3 == 2) {
-                // used when the 512-voxel tiles still fill the 256 CUs evenly (>= 90 % of the last round) and do not add
-                // padding rows; e.g. 48x128x128 and 48x64x64 volumes yes, 48x32x32 with 512 couts (384 blocks) no
-                const long long t512 = (long long)d.n * ceil_div(p->Dr, 4) * ceil_div(p->Hr, 4) * ceil_div(p->Wr, 32);
-                const long long b512 = t512 * ceil_div(d.cout, 128);
-                const double fill = (double)b512 / (double)(((b512 + 255) / 256) * 256);
-                const char* m5 = getenv("CTSI_CONV_M512");   // "0" | "1" (tuning aid)
-                const bool want = (fill >= 0.9 && t512 * 512 <= padded32 * 11 / 10 * d.n) || (m5 && !strcmp(m5, "1"));
-                if (want && !(m5 && !strcmp(m5, "0"))) {
+                // 512-voxel (4x4x32) tiles, 16-channel chunks: used when they still fill the 256 CUs evenly (>= 90 % of the
+                // last round) and do not add padding rows: 48x128x128 and 48x64x64 volumes yes, 48x32x32 with 512 couts (384
+                // blocks) no.  The 384-voxel (6x2x32, 6 waves) tile would give that level 512 blocks, but interleaved A/B
+                // timing has it 6 % behind the 4x2x32 kernel (1150 vs 1219 TFLOP/s: 6 waves load the 4 SIMDs 2/2/1/1) -> opt-in.
+                auto fill = [&](int td, int th, long long* vox) {
+                    const long long t = (long long)d.n * ceil_div(p->Dr, td) * ceil_div(p->Hr, th) * ceil_div(p->Wr, 32);
+                    const long long b = t * ceil_div(d.cout, 128);
+                    *vox = t * td * th * 32;
+                    return (double)b / (double)(((b + 255) / 256) * 256);
+                };
+                long long v512 = 0, v384 = 0;
+                const double f512 = fill(4, 4, &v512), f384 = fill(6, 2, &v384);
+                const long long vmax = padded32 * 11 / 10 * d.n;
+                const char* m5 = getenv("CTSI_CONV_M512");   // "0" | "1" | "62" (tuning aid)
+                int pick = 0;
+                if (f512 >= 0.9 && v512 <= vmax) pick = 1;
+                (void)f384;
+                if (m5 && !strcmp(m5, "1")) pick = 1;
+                if (m5 && !strcmp(m5, "62")) pick = 2;
+                if (m5 && !strcmp(m5, "0")) pick = 0;
+                if (pick) {
                     p->halo3 = 5;
-                    p->BM = 512;
+                    p->BM = pick == 1 ? 512 : 384;
+                    p->m512_62 = pick == 2;
                 }
             }
         }
@@ -701,7 +716,7 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
     if (p->halo3 == 5) {
-        p->TD = 4; p->TH = 4; p->TW = 32;
+        p->TD = p->m512_62 ? 6 : 4; p->TH = p->m512_62 ? 2 : 4; p->TW = 32;
     } else if (p->halo3 >= 2) {
         p->TD = 4; p->TH = 2; p->TW = 32;
     } else if (p->halo3) {
@@ -873,7 +888,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
         }
         if (p->halo3 == 4) return ctsi_conv3_halo_n64_launch(&h, stream);
-        if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, stream);
+        if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, p->m512_62, stream);
         if (p->halo3 == 3) {
             static int ncu = 0;
             if (!ncu) {

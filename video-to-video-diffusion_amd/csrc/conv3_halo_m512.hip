@@ -62,7 +62,7 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     constexpr int HALO_INSTR = Cfg::HALO_INSTR, HALO_BYTES = Cfg::HALO_BYTES, BM = Cfg::BM, BN = Cfg::BN;
     constexpr int TAP_BYTES = Cfg::TAP_BYTES, WSLOT_BYTES = Cfg::WSLOT_BYTES, NWS = Cfg::NWS, NWAVE = Cfg::NWAVE;
     constexpr int NTH = Cfg::NTH, NPIECE = Cfg::NPIECE, OFF_W = Cfg::OFF_W, OFF_ROW = Cfg::OFF_ROW, OFF_CS = Cfg::OFF_CS;
-    static_assert(TD > 0, "");
+    (void)TD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long* s_rowoff = reinterpret_cast<long long*>(smem + OFF_ROW);
     float* s_cs = reinterpret_cast<float*>(smem + OFF_CS);
@@ -209,7 +209,7 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     // prologue: halo of chunk 0, weights of steps 0..3
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) issue_halo(0, i, 0);
-    int n_prev1 = 0, n_prev2 = 0, n_prev3 = 0;   // DMAs this wave issued in each of the previous three steps (wave-uniform)
+    int n_prev1 = 0, n_prev2 = 0;   // DMAs this wave issued in the previous step / the one before (wave-uniform)
 #pragma unroll
     for (int s = 0; s < NWS; ++s)
         if (s < S) issue_weights(s);
@@ -226,16 +226,15 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
         const int kd = g / 3, kh = g - kd * 3;
         const int vs = (kd * HH + kh) * HW;
         HN_PHASE(fa0, fb0, fa2, fb2, hbuf, wbuf, vs, 2);
-        // slot s is drained by this wave once the loads above have returned.  Needed next: weights of step s+1 (issued NWS-1
-        // steps ago); the next chunk's halo pieces are issued at g = 0..4, so they are older than the NWS-2 most recent
+        // slot s is drained by this wave once the loads above have returned.  Needed next: weights of step s+1 (issued 3
+        // steps ago); the next chunk's halo pieces are issued at g < NPIECE <= 6, so they are older than the two most recent
         // steps' DMAs by the time they are read (g = 8).
-        hm_wait_vm(n_prev1 + n_prev2 + (NWS > 4 ? n_prev3 : 0));
+        hm_wait_vm(n_prev1 + n_prev2);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         int issued = 0;
         if (s + NWS < S && !(p.dbg & 2)) issued += issue_weights(s + NWS);
         if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1)) issued += issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
-        n_prev3 = n_prev2;
         n_prev2 = n_prev1;
         n_prev1 = issued;
         int g2 = g + 1, cc2 = cc;

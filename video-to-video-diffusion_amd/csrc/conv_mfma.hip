@@ -695,13 +695,12 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                     *vox = t * td * th * 32;
                     return (double)b / (double)(((b + 255) / 256) * 256);
                 };
-                long long v512 = 0, v384 = 0;
-                const double f512 = fill(4, 4, &v512), f384 = fill(6, 2, &v384);
+                long long v512 = 0;
+                const double f512 = fill(4, 4, &v512);
                 const long long vmax = padded32 * 11 / 10 * d.n;
                 const char* m5 = getenv("CTSI_CONV_M512");   // "0" | "1" | "62" (tuning aid)
                 int pick = 0;
                 if (f512 >= 0.9 && v512 <= vmax) pick = 1;
-                (void)f384;
                 if (m5 && !strcmp(m5, "1")) pick = 1;
                 if (m5 && !strcmp(m5, "62")) pick = 2;
                 if (m5 && !strcmp(m5, "0")) pick = 0;

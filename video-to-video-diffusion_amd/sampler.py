@@ -191,18 +191,27 @@ class DDIMSampler:
 
     @torch.no_grad()
     def sample(self, shape, conditioning, num_inference_steps, device, eta=0.0, progress=True, noise_fn=None,
-               trajectory=None):
+               trajectory=None, z_init=None):
         t_desc = [int(t) for t in self._get_timesteps(num_inference_steps)]
         return run_sampler(self.diffusion, self.model, shape, conditioning, device, kind="ddim", t_desc=t_desc,
-                           progress=progress, eta=float(eta), noise_fn=noise_fn, trajectory=trajectory)
+                           progress=progress, eta=float(eta), noise_fn=noise_fn, trajectory=trajectory, z_init=z_init)
 
     @torch.no_grad()
     def sample_with_stitching(self, v_thick_full, vae, num_inference_steps=20, patch_size=(8, 192, 192),
                               target_patch_size=(48, 192, 192), stride=(4, 96, 96), device='cuda', eta=0.0,
-                              progress=True):
+                              progress=True, window_batch=8):
+        """`window_batch` (additive kwarg): windows are independent, so for the deterministic sampler (eta == 0) up to
+        that many are encoded / sampled / decoded as one batch -- a single 192x192 patch leaves most of an MI355X
+        idle (its coarsest level has 28 conv tiles for 256 CUs).  The initial noise of every window is still drawn
+        with its own `torch.randn` call in window order, exactly as the reference's one-by-one loop draws it."""
+        batched = None
+        if float(eta) == 0.0 and window_batch > 1:
+            batched = lambda shp, cond, z_init: self.sample(shp, cond, num_inference_steps, device, eta=0.0,
+                                                            progress=False, z_init=z_init)
         return _stitched(self, v_thick_full, vae, patch_size, target_patch_size, stride, device, progress,
                          lambda shp, cond: self.sample(shp, cond, num_inference_steps, device, eta=eta,
-                                                       progress=False))
+                                                       progress=False),
+                         batched_fn=batched, window_batch=window_batch)
 
     def _create_gaussian_weight(self, d, h, w):
         return gaussian_weight(d, h, w)
@@ -222,7 +231,8 @@ def _axis_window(n: int) -> torch.Tensor:
     return torch.exp(-(x ** 2) / (2 * (n / 6) ** 2))
 
 
-def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride, device, progress, sample_fn):
+def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride, device, progress, sample_fn,
+              batched_fn=None, window_batch=1):
     """Sliding-window inference (sampler.py:63-172, 338-453): per window encode -> sample -> decode on the
     engine, Gaussian-weighted accumulation (ctsi_blend_accumulate) and final normalisation
     (ctsi_blend_normalize) on device.
@@ -260,20 +270,37 @@ def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride,
         dist = None
     from .parallel import shard_units
     mine = [windows[i] for i in shard_units(len(windows), rank, world)]
-    it = mine
+    it = None
     if progress and tqdm is not None:
-        it = tqdm(mine, desc="Patch-based inference", total=len(mine))
-    for (ds, hs, ws) in it:
-        patch = v_thick_full[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw].to(ctx.device).contiguous()
-        z_cond = vae.encode(patch)
+        it = tqdm(desc="Patch-based inference", total=len(mine))
+    group = max(1, int(window_batch)) if batched_fn is not None else 1
+    ngroups = max(1, -(-len(mine) // group))            # balanced groups: 25 windows, window_batch 8 -> 7 + 6 + 6 + 6
+    bounds = [round(i * len(mine) / ngroups) for i in range(ngroups + 1)]
+    for gi in range(ngroups):
+        wins = mine[bounds[gi]:bounds[gi + 1]]
+        if not wins:
+            continue
+        patch = torch.cat([v_thick_full[:, :, ds:ds + pd, hs:hs + ph, ws:ws + pw] for (ds, hs, ws) in wins], dim=0)
+        z_cond = vae.encode(patch.to(ctx.device).contiguous())
         if td != pd:
             with ctx.scope():
                 z_cond = trilinear_depth(ctx, z_cond, td)
-        z = sample_fn(tuple(z_cond.shape), z_cond)
+        if len(wins) == 1 or batched_fn is None:
+            z = sample_fn(tuple(z_cond.shape), z_cond)
+        else:   # one torch.randn per window, in window order (the reference's RNG stream)
+            one = (b,) + tuple(z_cond.shape[1:])
+            z_init = torch.cat([torch.randn(one, device=ctx.device) for _ in wins], dim=0)
+            z = batched_fn(tuple(z_cond.shape), z_cond, z_init)
         out = vae.decode(z).contiguous()
         with ctx.scope():
-            lib.blend_accumulate(_ptr(acc), _ptr(wsum), _ptr(out), _ptr(wd), _ptr(wh), _ptr(ww), b * c, td, th, tw,
-                                 d_thin, hf, wf, int(ds * ratio), hs, ws, sptr)
+            for k, (ds, hs, ws) in enumerate(wins):
+                ok = out[k * b:(k + 1) * b]
+                lib.blend_accumulate(_ptr(acc), _ptr(wsum), _ptr(ok), _ptr(wd), _ptr(wh), _ptr(ww), b * c, td, th, tw,
+                                     d_thin, hf, wf, int(ds * ratio), hs, ws, sptr)
+        if progress and tqdm is not None:
+            it.update(len(wins))
+    if it is not None:
+        it.close()
     if world > 1:
         dist.all_reduce(acc)
         dist.all_reduce(wsum)

@@ -18,7 +18,7 @@
 // Epilogue: + bias, optional tanh, bf16 tile transposed through LDS for full-line 16-B stores
 // (or strided fp32 stores for the few-channel output layers), and per-tile column sums
 // (sum, sum of squares) for the GroupNorm that follows every large conv on this path.
-#include "ctsi_internal.h"
+#include "conv3_halo_common.h"
 #include <string.h>
 #include <stdlib.h>
 #include <math.h>
@@ -78,15 +78,20 @@ __global__ void __launch_bounds__(WM* WN * 64)
 conv_gather_mfma_kernel(const ConvKParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (buffer-resource builtins are device-only)
     constexpr bool SMALL = (MODE == 1);
-    constexpr bool FAST = (MODE == 2);
+    constexpr bool FAST = (MODE == 2 || MODE == 3);
+    // MODE 3: the buffer-addressed path with a deep LDS ring and inline-asm DMA (counted vmcnt waits): for launches with
+    // at most ~2 blocks per CU, where a 2-stage pipeline exposes the full DMA latency in every K-step
+    constexpr bool RING = (MODE == 3);
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NW = WM * WN, NTH = NW * 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
     static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
     static_assert(BM * BN * 2 <= 2 * STAGE, "epilogue tile must fit the stages");
+    constexpr int NSTG = RING ? (STAGE <= 32768 ? 4 : (STAGE <= 49152 ? 3 : 2)) : 2;
+    constexpr int DPS = A_INSTR + B_INSTR;   // DMA instructions per wave and K-step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    long long* s_rowoff = reinterpret_cast<long long*>(smem + 2 * STAGE);
+    long long* s_rowoff = reinterpret_cast<long long*>(smem + NSTG * STAGE);
 
     if (p.dbg & 8) return;
     const int tid = threadIdx.x;
@@ -216,8 +221,51 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         }
     }
 
+    v4i_t rr1, rr2, rrw;   // MODE 3: the same descriptors as SGPR quads for the inline-asm DMA
+    unsigned lds0 = 0;
+    if (RING) {
+        int dlo = d0 + p.dshift + p.ad_min[cls];
+        dlo = dlo < 0 ? 0 : dlo;
+        const long long basevox = ((long long)(nb * p.Di + dlo) * p.Hi) * p.Wi;
+        rr1 = h3_make_rsrc(x1c + (basevox - margin) * C1 * 2, 0x7fffffffu);
+        rr2 = h3_make_rsrc(reinterpret_cast<const char*>(p.x2) + (basevox - margin) * C2 * 2, 0x7fffffffu);
+        rrw = h3_make_rsrc(wbase, 0x7fffffffu);
+        lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;
+    }
+
     auto stage = [&](int s, char* buf) {
         char* a_dst = buf + wave * (A_INSTR * 1024);
+        if (RING) {
+            const int ch0 = st_cc * 64;
+            const bool second = ch0 >= C1;
+            const int td = p.tapdelta[tapbase + st_tap] + margin;
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(
+                (int)(second ? (unsigned)td * (unsigned)(C2 * 2) + (unsigned)(ch0 - C1) * 2
+                             : (unsigned)td * (unsigned)(C1 * 2) + (unsigned)ch0 * 2));
+            const unsigned abase = lds0 + (unsigned)(a_dst - smem);
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) {
+                const bool ok = ((a_mask[i] >> st_tap) & 1ull) != 0ull;
+                const unsigned voff = ok ? (second ? a_voff2[i] : a_voff1[i]) : 0x80000000u;
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(abase + i * 1024));
+                if (second)
+                    h3_dma16(rr2, dst, voff, soff);
+                else
+                    h3_dma16(rr1, dst, voff, soff);
+            }
+            const unsigned bbase = lds0 + (unsigned)(buf - smem) + A_BYTES + wave * (B_INSTR * 1024);
+            const unsigned wsoff = (unsigned)__builtin_amdgcn_readfirstlane(s * 128);
+#pragma unroll
+            for (int i = 0; i < B_INSTR; ++i) {
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(bbase + i * 1024));
+                h3_dma16(rrw, dst, b_voff[i], wsoff);
+            }
+            if (++st_tap == p.T) {
+                st_tap = 0;
+                ++st_cc;
+            }
+            return;
+        }
         if (FAST) {
             const int ch0 = st_cc * 64;
             const bool second = ch0 >= C1;
@@ -286,12 +334,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     for (int kk = 0; kk < 4; ++kk) koff[kk] = (((kk * 2 + (lane >> 5)) ^ fsw) << 4) + frow;
 
     const int S = p.ksteps;
-    if (!(p.dbg & 4)) stage(0, smem);
-    for (int s = 0; s < S; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        char* cur = smem + (s & 1) * STAGE;
-        if (s + 1 < S) stage(s + 1, smem + ((s + 1) & 1) * STAGE);
+    auto compute = [&](const char* cur) {
         const char* a_base = cur + (wm * TM * 32) * 128;
         const char* b_base = cur + A_BYTES + (wn * TN * 32) * 128;
 #pragma unroll
@@ -309,13 +352,41 @@ conv_gather_mfma_kernel(const ConvKParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+    };
+    if (RING) {
+        // ring of NSTG stages: the DMAs of step s+NSTG-1 are issued while step s is on the matrix cores; the wait only
+        // requires step s to have landed ((NSTG-2) * DPS younger DMA instructions of this wave may stay in flight)
+#pragma unroll
+        for (int i = 0; i < NSTG - 1; ++i)
+            if (i < S) stage(i, smem + i * STAGE);
+        int slot = 0;
+        for (int s = 0; s < S; ++s) {
+            if (s + NSTG - 2 < S)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * DPS) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + NSTG - 1 < S) stage(s + NSTG - 1, smem + (slot == 0 ? NSTG - 1 : slot - 1) * STAGE);
+            compute(smem + slot * STAGE);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            slot = (slot + 1 == NSTG) ? 0 : slot + 1;
+        }
+    } else {
+        if (!(p.dbg & 4)) stage(0, smem);
+        for (int s = 0; s < S; ++s) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            char* cur = smem + (s & 1) * STAGE;
+            if (s + 1 < S) stage(s + 1, smem + ((s + 1) & 1) * STAGE);
+            compute(cur);
+        }
     }
     __syncthreads();  // every wave is done with the stage buffers
     if (p.dbg & 2) return;
 
     // ---- epilogue --------------------------------------------------------------------------------
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);                          // [BM][BN]
-    float* s_cs = reinterpret_cast<float*>(smem + 2 * STAGE + BM * 8);         // [WM][BN][2]
+    float* s_cs = reinterpret_cast<float*>(smem + NSTG * STAGE + BM * 8);      // [WM][BN][2]
     const int lhi = lane >> 5, lcol = lane & 31;
     const bool want_sums = p.colsum != nullptr;
     // validity of the 16*TM rows this lane's accumulators belong to (bit r of vbits[i])
@@ -830,8 +901,13 @@ template <int WM, int WN, int TM, int TN>
 static int launch_conv(const ConvKParams& k, int mode, int grid, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr size_t lds = 2 * (BM * 128 + BN * 128) + BM * 8 + WM * BN * 8;
+    constexpr int STAGE = BM * 128 + BN * 128;
+    constexpr int NSTG = STAGE <= 32768 ? 4 : (STAGE <= 49152 ? 3 : 2);
+    constexpr size_t lds_ring = (size_t)NSTG * STAGE + BM * 8 + WM * BN * 8;
     static bool attr_done = false;
     if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, 3>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ring);
         hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, 0>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, 1>,
@@ -843,6 +919,8 @@ static int launch_conv(const ConvKParams& k, int mode, int grid, hipStream_t st)
     const dim3 g(grid), b(WM * WN * 64);
     if (mode == 1)
         hipLaunchKernelGGL((conv_gather_mfma_kernel<WM, WN, TM, TN, 1>), g, b, lds, st, k);
+    else if (mode == 3)
+        hipLaunchKernelGGL((conv_gather_mfma_kernel<WM, WN, TM, TN, 3>), g, b, lds_ring, st, k);
     else if (mode == 2)
         hipLaunchKernelGGL((conv_gather_mfma_kernel<WM, WN, TM, TN, 2>), g, b, lds, st, k);
     else
@@ -941,7 +1019,13 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
     k.dshift = p->dshift;
     memcpy(k.tap_margin, p->tap_margin, sizeof(k.tap_margin));
     memcpy(k.ad_min, p->ad_min, sizeof(k.ad_min));
-    const int mode = p->small ? 1 : (p->fast ? 2 : 0);
+    int mode = p->small ? 1 : (p->fast ? 2 : 0);
+    {   // deep-ring variant for launches that cannot hide DMA latency behind other blocks of the same CU
+        static const char* ring = getenv("CTSI_CONV_RING");   // "0" | "1" (tuning aid)
+        const bool small_grid = grid <= 256 && !(p->BM == 256 && p->BN == 256);   // at most one block per CU: the ring's
+                                                                                   // 128-144 KB of LDS evict no second block
+        if (mode == 2 && ((small_grid && !(ring && !strcmp(ring, "0"))) || (ring && !strcmp(ring, "1")))) mode = 3;
+    }
     if (p->BM == 256 && p->BN == 256) return launch_conv<2, 4, 4, 2>(k, mode, grid, st);
     if (p->BM == 256 && p->BN == 128) return launch_conv<4, 2, 2, 2>(k, mode, grid, st);
     if (p->BN == 128) return launch_conv<2, 2, 2, 2>(k, mode, grid, st);

@@ -750,7 +750,7 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             // issues 64 two-byte stores per wave, 0.084 ms of a 0.85 ms layer) -> opt-in only, see profiles/r01_notes.md
             if (p->halo3 == 2 && getenv("CTSI_CONV_PERSIST") && !getenv("CTSI_CONV_NO_PERSIST")) p->halo3 = 3;
             // half-size blocks (4 waves, 64 couts, 16-channel chunks, two blocks per CU): conv3_halo_n64.hip
-            if (p->halo3 == 2 && getenv("CTSI_CONV_N64")) {
+            if (p->halo3 == 2 && getenv("CTSI_CONV_N64") && !strcmp(getenv("CTSI_CONV_N64"), "1")) {
                 p->halo3 = 4;
                 p->BN = 64;
             }

@@ -735,7 +735,6 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                         d.pd == 1 && d.ph == 1 && d.pw == 1;
         const long long rows = (long long)p->Dr * p->Hr * p->Wr;
         const long long padded = (long long)ceil_div(p->Dr, 4) * ceil_div(p->Hr, 4) * ceil_div(p->Wr, 16) * 256;
-        const long long padded32 = (long long)ceil_div(p->Dr, 4) * ceil_div(p->Hr, 2) * ceil_div(p->Wr, 32) * 256;
         const int cmax = d.c1 > d.c2 ? d.c1 : d.c2;
         const double extent = 8.0 * d.hi * d.wi * cmax * 2.0;
         p->halo3 = k3 && !p->small && d.c1 % 32 == 0 && d.c2 % 32 == 0 && d.cout >= 64 && d.cout % 8 == 0 &&
@@ -744,42 +743,37 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
         if (p->halo3) {
             p->BM = 256;
             p->BN = 128;
-            const char* hv = getenv("CTSI_CONV_HALO_TILE");   // "16" | "32" (tuning aid)
-            if ((padded32 <= padded && !(hv && !strcmp(hv, "16"))) || (hv && !strcmp(hv, "32"))) p->halo3 = 2;
+            // Which of the three halo-tile kernels: score = useful fraction of the tile rows x fill of the 256 CUs (blocks /
+            // whole rounds) x the kernel's measured relative efficiency on full grids (16-wide 0.85, 4x2x32 1.0, 4x4x32 / 512
+            // voxels 1.1).  Reproduces every interleaved A/B measurement of profiles/r01_notes.md: 48x128^2 and 48x64^2 -> 512-voxel
+            // tile, 48x32^2 x 512 couts -> 4x2x32 (384 big blocks would idle a quarter of the CUs), 48x16^2 and 48x48^2 ->
+            // 16-wide, a lone 48x24^2 level (144 blocks either way) -> 512-voxel tile.
+            auto score = [&](int td, int th, int tw, double eff) {
+                const long long t = (long long)d.n * ceil_div(p->Dr, td) * ceil_div(p->Hr, th) * ceil_div(p->Wr, tw);
+                const long long b = t * ceil_div(d.cout, 128);
+                const double useful = (double)rows * d.n / ((double)t * td * th * tw);
+                return useful * (double)b / (double)(((b + 255) / 256) * 256) * eff;
+            };
+            const double s16 = score(4, 4, 16, 0.85), s32 = score(4, 2, 32, 1.0), s512 = score(4, 4, 32, 1.1);
+            int pick = s16 >= s32 && s16 >= s512 ? 1 : (s32 >= s512 ? 2 : 5);
+            const char* hv = getenv("CTSI_CONV_HALO_TILE");   // "16" | "32" (tuning aids)
+            const char* m5 = getenv("CTSI_CONV_M512");        // "0" | "1" | "62"
+            if (hv && !strcmp(hv, "16")) pick = 1;
+            if (hv && !strcmp(hv, "32") && pick == 1) pick = s32 >= s512 ? 2 : 5;
+            if (m5 && !strcmp(m5, "0") && pick == 5) pick = 2;
+            if (m5 && (!strcmp(m5, "1") || !strcmp(m5, "62")) && pick != 1) pick = 5;
+            p->halo3 = pick;
+            if (pick == 5) {
+                p->m512_62 = m5 && !strcmp(m5, "62");     // 384-voxel 6x2x32 tile: measured behind the 4x2x32 kernel, opt-in
+                p->BM = p->m512_62 ? 384 : 512;
+            }
             // persistent-block variant: measured slower than the one-tile-per-block kernel (its register epilogue
             // issues 64 two-byte stores per wave, 0.084 ms of a 0.85 ms layer) -> opt-in only, see profiles/r01_notes.md
             if (p->halo3 == 2 && getenv("CTSI_CONV_PERSIST") && !getenv("CTSI_CONV_NO_PERSIST")) p->halo3 = 3;
-            // half-size blocks (4 waves, 64 couts, 16-channel chunks, two blocks per CU): conv3_halo_n64.hip
+            // half-size blocks (4 waves, 64 couts, 16-channel chunks, two blocks per CU): conv3_halo_n64.hip, opt-in
             if (p->halo3 == 2 && getenv("CTSI_CONV_N64") && !strcmp(getenv("CTSI_CONV_N64"), "1")) {
                 p->halo3 = 4;
                 p->BN = 64;
-            }
-            // 512-voxel tile (4 x 4 x 32) x 128 couts, 16-channel chunks: half the weight DMA pieces per MFMA (conv3_halo_m512.hip)
-            if (p->halo3 == 2) {
-                // 512-voxel (4x4x32) tiles, 16-channel chunks: used when they still fill the 256 CUs evenly (>= 90 % of the
-                // last round) and do not add padding rows: 48x128x128 and 48x64x64 volumes yes, 48x32x32 with 512 couts (384
-                // blocks) no.  The 384-voxel (6x2x32, 6 waves) tile would give that level 512 blocks, but interleaved A/B
-                // timing has it 6 % behind the 4x2x32 kernel (1150 vs 1219 TFLOP/s: 6 waves load the 4 SIMDs 2/2/1/1) -> opt-in.
-                auto fill = [&](int td, int th, long long* vox) {
-                    const long long t = (long long)d.n * ceil_div(p->Dr, td) * ceil_div(p->Hr, th) * ceil_div(p->Wr, 32);
-                    const long long b = t * ceil_div(d.cout, 128);
-                    *vox = t * td * th * 32;
-                    return (double)b / (double)(((b + 255) / 256) * 256);
-                };
-                long long v512 = 0;
-                const double f512 = fill(4, 4, &v512);
-                const long long vmax = padded32 * 11 / 10 * d.n;
-                const char* m5 = getenv("CTSI_CONV_M512");   // "0" | "1" | "62" (tuning aid)
-                int pick = 0;
-                if (f512 >= 0.9 && v512 <= vmax) pick = 1;
-                if (m5 && !strcmp(m5, "1")) pick = 1;
-                if (m5 && !strcmp(m5, "62")) pick = 2;
-                if (m5 && !strcmp(m5, "0")) pick = 0;
-                if (pick) {
-                    p->halo3 = 5;
-                    p->BM = pick == 1 ? 512 : 384;
-                    p->m512_62 = pick == 2;
-                }
             }
         }
     }

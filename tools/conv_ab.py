@@ -8,7 +8,7 @@ E = importlib.import_module("video-to-video-diffusion_amd.engine")
 ap = argparse.ArgumentParser()
 ap.add_argument("var"); ap.add_argument("a"); ap.add_argument("b")
 ap.add_argument("--cin", type=int, default=512); ap.add_argument("--cout", type=int, default=512)
-ap.add_argument("--dhw", type=int, nargs=3, default=[48, 32, 32]); ap.add_argument("--rounds", type=int, default=6)
+ap.add_argument("--dhw", type=int, nargs=3, default=[48, 32, 32]); ap.add_argument("--rounds", type=int, default=6); ap.add_argument("--n", type=int, default=1)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 ctx = E.Ctx.get(dev)
@@ -20,7 +20,7 @@ with ctx.scope():
     for val in (a.a, a.b):
         os.environ[a.var] = val
         prog = E.Program(ctx)
-        x = prog.act(1, a.cin, d, h, w)
+        x = prog.act(a.n, a.cin, d, h, w)
         x.t.normal_()
         prog.zero_gn_op()
         prog.conv("c", lambda: wt, lambda: b, x, None, cout=a.cout, want_stats=True)

@@ -15,6 +15,7 @@ ap.add_argument("--hw", type=int, default=512)
 ap.add_argument("--depth", type=int, default=48)
 ap.add_argument("--net", default="unet")
 ap.add_argument("--repeats", type=int, default=3)
+ap.add_argument("--batch", type=int, default=1)
 args = ap.parse_args()
 pkg = importlib.import_module("video-to-video-diffusion_amd")
 E = importlib.import_module("video-to-video-diffusion_amd.engine")
@@ -24,10 +25,11 @@ model = pkg.VideoToVideoDiffusion(bench.EFFECTIVE_CFG).eval().to(dev)
 ctx = E.Ctx.get(dev)
 with ctx.scope():
     if args.net == "unet":
-        prog = E.UNetProgram(ctx, model.unet, 1, args.depth, args.hw // 4, args.hw // 4, max_rows=4)
-        prog.load_latents(torch.randn(1, 8, args.depth, args.hw // 4, args.hw // 4, device=dev),
-                          torch.randn(1, 8, args.depth, args.hw // 4, args.hw // 4, device=dev))
-        prog.set_schedule([500])
+        nb = args.batch
+        prog = E.UNetProgram(ctx, model.unet, nb, args.depth, args.hw // 4, args.hw // 4, max_rows=4 * nb)
+        prog.load_latents(torch.randn(nb, 8, args.depth, args.hw // 4, args.hw // 4, device=dev),
+                          torch.randn(nb, 8, args.depth, args.hw // 4, args.hw // 4, device=dev))
+        prog.set_schedule([500] * nb)
     elif args.net == "dec":
         prog = E.VAEDecodeProgram(ctx, model.vae, 1, args.depth, args.hw // 4, args.hw // 4)
     else:

@@ -64,8 +64,10 @@ conv_wgrad_kernel(const WgradParams p) {
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- block decode: tap fastest (neighbouring blocks share both slabs in L2), then tiles, then slice ----
-    int bid = blockIdx.x;
+    // ---- block decode: tap fastest, then tiles, then slice.  Hardware deals consecutive block ids round-robin to the 8
+    // XCDs; the remap gives every XCD a contiguous range of logical ids, so the 27 taps of one voxel slice (which read the
+    // same R slab and neighbouring G rows) meet in ONE L2 instead of being fetched by eight ------------------------------------
+    int bid = xcd_remap_h((int)blockIdx.x, (int)gridDim.x);
     const int t = bid % p.T;
     bid /= p.T;
     const int tg = bid % p.tiles_g;
@@ -235,7 +237,7 @@ conv_wgrad_s1_kernel(const WgradParams p) {
 
     // ---- block decode: tap group fastest, then tiles, then slice ---------------------------------------------------
     const int ngroups = p.T / TG;
-    int bid = blockIdx.x;
+    int bid = xcd_remap_h((int)blockIdx.x, (int)gridDim.x);
     const int grp = bid % ngroups;
     bid /= ngroups;
     const int tg = bid % p.tiles_g;

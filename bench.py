@@ -212,10 +212,16 @@ def bench_train(args, pkg, E, model, ctx, dev, rank, world, dist):
         wg = groups.get("wgrad")
         roof = None
         if wg:
+            traffic = None
+            try:  # HBM bytes per launch from rocprofv3 --pmc passes over tools/profile_train.py (tools/pmc_traffic.py)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_train.json")))["kernels"]
+                traffic = pmc["conv_wgrad_kernel"]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             ach = wg[1] / (wg[2] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv_wgrad_kernel (transposing-LDS-read MFMA weight gradient)",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                    "traffic": None, "launches_per_step": wg[0], "avg_launch_ms": wg[2] / wg[0],
+                    "traffic": traffic, "launches_per_step": wg[0], "avg_launch_ms": wg[2] / wg[0],
                     "groups": {k: {"launches": v[0], "tflops": (v[1] / (v[2] * 1e-3) / 1e12) if v[1] else None,
                                    "ms": v[2]} for k, v in groups.items()}}
         print(json.dumps({

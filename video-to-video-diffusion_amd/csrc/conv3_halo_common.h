@@ -33,6 +33,24 @@ __device__ __forceinline__ void h3_dma16(const v4i_t rsrc, unsigned lds_addr, un
         : "memory");
 }
 
+// (m-tile, n-tile) of a block.  order 0: the n-tiles of one m-tile are neighbours (they share the halo in L2).
+// order 1 (n_major): inside the contiguous range of logical ids an XCD owns, blocks walk all m-tiles of n-tile 0, then
+// n-tile 1, ...: the CUs of an XCD then stream ONE n-tile's weight slab at a time (3.5 MB for 128 couts x 512 cin x 27,
+// which fits the 4 MB L2), instead of all n-tiles' slabs at once (14 MB: every round re-fetches them from HBM).
+// Needs mtiles % 8 == 0 (each XCD owns whole m-tiles x all n-tiles); otherwise order 0 is used.
+__device__ __forceinline__ void h3_decode_tile(int bid, int mtiles, int ntiles_n, int n_major, int* mt, int* nt) {
+    if (n_major && (mtiles & 7) == 0) {
+        const int per_xcd = (mtiles >> 3) * ntiles_n;
+        const int x = bid / per_xcd, local = bid - x * per_xcd;
+        const int mcount = mtiles >> 3;
+        *nt = local / mcount;
+        *mt = x * mcount + (local - *nt * mcount);
+    } else {
+        *mt = bid / ntiles_n;
+        *nt = bid - *mt * ntiles_n;
+    }
+}
+
 __device__ __forceinline__ int xcd_remap_h(int orig, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;

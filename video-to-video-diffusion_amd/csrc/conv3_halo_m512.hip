@@ -73,8 +73,8 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     const int wm = wave;
 
     const int bid = xcd_remap_h(blockIdx.x, gridDim.x);
-    const int mt = bid / p.ntiles_n;
-    const int nt = bid - mt * p.ntiles_n;
+    int mt, nt;
+    h3_decode_tile(bid, p.mtiles, p.ntiles_n, p.n_major, &mt, &nt);
     const int n0 = nt * BN;
     const int nb = mt / p.tps;
     int r0 = mt - nb * p.tps;

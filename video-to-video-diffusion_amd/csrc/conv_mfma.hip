@@ -952,6 +952,12 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         h.nchunks = p->Cin / (p->halo3 >= 4 ? 16 : 32);
         h.Cout = p->d.cout; h.CoutPad = p->CoutPad;
         h.cout_stride = o->cout_stride; h.c_off = o->c_off;
+        {   // n-major block order (one n-tile's 3.5 MB weight slab at a time per XCD instead of all of them: the 48x32x32 /
+            // 512-cout layers move 508 MB of HBM traffic per launch against 114 MB algorithmic because 14 MB of weights
+            // thrash the 4 MB L2).  Interleaved timing shows no speed difference (1214 vs 1211 TFLOP/s), so it stays opt-in.
+            const char* nm = getenv("CTSI_CONV_NMAJOR");   // "1" (tuning aid; read per launch)
+            h.n_major = nm ? atoi(nm) : 0;
+        }
         {
             static const char* dbgf = getenv("CTSI_DEBUG_FLAGS");
             h.dbg = dbgf ? atoi(dbgf) : 0;

@@ -86,6 +86,7 @@ struct Conv3HaloParams {
     int nchunks;          // (C1 + C2) / 32
     int Cout, CoutPad;
     int cout_stride, c_off;
+    int n_major;          // block order inside an XCD: 1 = all m-tiles of one n-tile first (see h3_decode_tile)
     int dbg;              // timing-only ablation bits (0 in production): 1 no halo DMA after chunk 0, 2 no weight DMA after step 1
 };
 

@@ -119,7 +119,7 @@ HALO3_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["16", "16t62", "32", "32p", "32n", "32m", "32m62"])
+@pytest.mark.parametrize("tile", ["16", "16t62", "16m", "32", "32p", "32n", "32m", "32m62"])
 @pytest.mark.parametrize("name,c1,c2,cout,dims", HALO3_CASES, ids=[c[0] for c in HALO3_CASES])
 def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     """The LDS halo-tile 3x3x3 kernel (conv3_halo.hip) on aligned, ragged, multi-tile and two-source inputs;
@@ -134,9 +134,10 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     groups = 8
     monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
     # 4x4x16 tile (16x16x32 MFMA), 4x2x32 tile (32x32x16 MFMA), the persistent-block or the half-size-block 4x2x32 kernel
-    monkeypatch.setenv("CTSI_CONV_HALO_TILE", tile[:2])
+    monkeypatch.setenv("CTSI_CONV_HALO_TILE", "32" if tile == "16m" else tile[:2])
+    monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile == "16m" else "0")     # 4x8x16 form of the 512-voxel kernel
     monkeypatch.setenv("CTSI_CONV_HALO16_TILE", "62" if tile == "16t62" else "44")   # 6x2x16 (6 waves) vs 4x4x16
-    monkeypatch.setenv("CTSI_CONV_M512", {"32m": "1", "32m62": "62"}.get(tile, "0"))   # 4x4x32 / 6x2x32 tiles, 16-ch chunks
+    monkeypatch.setenv("CTSI_CONV_M512", {"32m": "1", "32m62": "62", "16m": "1"}.get(tile, "0"))   # 4x4x32 / 6x2x32 tiles
     if tile == "32p":
         monkeypatch.setenv("CTSI_CONV_PERSIST", "1")
     if tile == "32n":       # half-size blocks: 4 waves x 64 couts x 16-channel chunks, two blocks per CU

@@ -14,9 +14,13 @@
 
 // Tile shapes: <4,4> = 4 x 4 x 32 = 512 voxels (8 waves) and <6,2> = 6 x 2 x 32 = 384 voxels (6 waves; a 48 x 32 x 32 level
 // with 512 couts gives 128 x 4 = 512 blocks = two full rounds on 256 CUs, where 512-voxel tiles give 384 blocks).
-template <int TD_, int TH_>
+// <4,8,16> = 4 x 8 x 16 = 512 voxels for levels whose width is a multiple of 16 but not of 32 (48-wide latents of 192^2
+// patches): an A tile of 32 rows is then two W-lines of 16 (lanes 16-31 read the next H line); with 32-byte rows that costs
+// 2-way bank conflicts on half of the A-fragment reads (no 1-bit slot swizzle separates rows 16 AND 24 apart), which the
+// 0.75 ds_read_b128 per MFMA of this kernel absorbs.
+template <int TD_, int TH_, int TW_ = 32>
 struct HmCfg {
-    static constexpr int TD = TD_, TH = TH_, TW = 32;
+    static constexpr int TD = TD_, TH = TH_, TW = TW_;
     static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
     static constexpr int HV = HD * HH * HW;                 // <4,4>: 1224 halo voxels
     static constexpr int HALO_INSTR = (HV + 31) / 32;       // <4,4>: 39 wave-DMAs of 32 voxels x 32 B
@@ -53,11 +57,11 @@ __device__ __forceinline__ void hm_wait_vm(int allowed) {   // wave-uniform `all
     }
 }
 
-template <int TD_, int TH_>
-__global__ void __attribute__((amdgpu_flat_work_group_size(1, HmCfg<TD_, TH_>::NTH)))
+template <int TD_, int TH_, int TW_ = 32>
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, HmCfg<TD_, TH_, TW_>::NTH)))
 conv3_halo32m_kernel(const Conv3HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using Cfg = HmCfg<TD_, TH_>;
+    using Cfg = HmCfg<TD_, TH_, TW_>;
     constexpr int TD = Cfg::TD, TH = Cfg::TH, TW = Cfg::TW, HH = Cfg::HH, HW = Cfg::HW, HV = Cfg::HV;
     constexpr int HALO_INSTR = Cfg::HALO_INSTR, HALO_BYTES = Cfg::HALO_BYTES, BM = Cfg::BM, BN = Cfg::BN;
     constexpr int TAP_BYTES = Cfg::TAP_BYTES, WSLOT_BYTES = Cfg::WSLOT_BYTES, NWS = Cfg::NWS, NWAVE = Cfg::NWAVE;
@@ -85,7 +89,7 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     const int d0 = tD * TD, h0 = tH * TH, w0 = tW * TW;
 
     {   // row = line*32 + m, line = ld*TH + lh
-        const int mm = tid & 31, line = tid >> 5;
+        const int mm = tid % TW, line = tid / TW;
         const int d = d0 + line / TH, h = h0 + line % TH, w = w0 + mm;
         long long off = -1;
         if (d < p.Do && h < p.Ho && w < p.Wo)
@@ -163,11 +167,11 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
 
     // fragment addressing: lane -> row r = lane & 31 of the 32-row operand tile, k-half hk = lane >> 5
     const int hk = lane >> 5, r = lane & 31;
-    int vline[2];                                            // halo voxel of this wave's two W-lines before taps
+    int vline[2];                                            // halo voxel of this lane's row in the wave's two A tiles, before taps
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int line = 2 * wm + i;
-        vline[i] = ((line / TH) * HH + (line % TH)) * HW + r;
+    for (int i = 0; i < 2; ++i) {                            // A tile = rows [(2*wm + i)*32, +32) = 32 / TW whole W-lines
+        const int line = (2 * wm + i) * (32 / TW) + r / TW;
+        vline[i] = ((line / TH) * HH + (line % TH)) * HW + r % TW;
     }
     const int b_off = r * 32 + ((hk ^ ((r >> 3) & 1)) << 4);    // n-tile j: + j*1024 (rows +32 keep (row>>3)&1)
 
@@ -331,19 +335,25 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile62, void* stream) {
+extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile62 /* 0: 4x4x32, 1: 6x2x32, 2: 4x8x16 */,
+                                           void* stream) {
     using C44 = HmCfg<4, 4>;
     using C62 = HmCfg<6, 2>;
+    using C48 = HmCfg<4, 8, 16>;
     auto k44 = conv3_halo32m_kernel<4, 4>;
     auto k62 = conv3_halo32m_kernel<6, 2>;
+    auto k48 = conv3_halo32m_kernel<4, 8, 16>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute((const void*)k44, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C44::LDS_BYTES);
         hipFuncSetAttribute((const void*)k62, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C62::LDS_BYTES);
+        hipFuncSetAttribute((const void*)k48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C48::LDS_BYTES);
         attr_done = true;
     }
     const int grid = hp->mtiles * hp->ntiles_n;
-    if (tile62)
+    if (tile62 == 2)
+        hipLaunchKernelGGL(k48, dim3(grid), dim3(C48::NTH), C48::LDS_BYTES, (hipStream_t)stream, *hp);
+    else if (tile62)
         hipLaunchKernelGGL(k62, dim3(grid), dim3(C62::NTH), C62::LDS_BYTES, (hipStream_t)stream, *hp);
     else
         hipLaunchKernelGGL(k44, dim3(grid), dim3(C44::NTH), C44::LDS_BYTES, (hipStream_t)stream, *hp);

@@ -551,7 +551,7 @@ struct ctsi_conv_plan {
     int tap_margin[4], ad_min[4];
     int fast, dshift;
     int halo16_62;  // halo3 == 1 only: 6x2x16 tile instead of 4x4x16
-    int m512_62;    // halo3 == 5 only: 6x2x32 (384 voxels) tile instead of 4x4x32
+    int m512_62;    // halo3 == 5 only: 1 = 6x2x32 (384 voxels) tile, 2 = 4x8x16 tile, instead of 4x4x32
     int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip);
                 // 3: 4x2x32 tile, persistent blocks (conv3_halo_persist.hip)
     double flops;
@@ -755,15 +755,24 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 return useful * (double)b / (double)(((b + 255) / 256) * 256) * eff;
             };
             const double s16 = score(4, 4, 16, 0.85), s32 = score(4, 2, 32, 1.0), s512 = score(4, 4, 32, 1.1);
+            const char* w16 = getenv("CTSI_CONV_M512W16");    // "0" | "1": the 4x8x16 form of the 512-voxel kernel
+            const double s512w = (w16 && !strcmp(w16, "0")) ? 0.0 : score(4, 8, 16, 1.0);
             int pick = s16 >= s32 && s16 >= s512 ? 1 : (s32 >= s512 ? 2 : 5);
+            bool use_w16 = s512w > s16 && s512w > s32 && s512w > s512;
+            if (w16 && !strcmp(w16, "1")) use_w16 = true;
             const char* hv = getenv("CTSI_CONV_HALO_TILE");   // "16" | "32" (tuning aids)
             const char* m5 = getenv("CTSI_CONV_M512");        // "0" | "1" | "62"
             if (hv && !strcmp(hv, "16")) pick = 1;
             if (hv && !strcmp(hv, "32") && pick == 1) pick = s32 >= s512 ? 2 : 5;
             if (m5 && !strcmp(m5, "0") && pick == 5) pick = 2;
             if (m5 && (!strcmp(m5, "1") || !strcmp(m5, "62")) && pick != 1) pick = 5;
+            if (use_w16 && !(hv && !strcmp(hv, "16")) && !(m5 && !strcmp(m5, "0"))) {
+                pick = 5;
+                p->m512_62 = 2;
+                p->BM = 512;
+            }
             p->halo3 = pick;
-            if (pick == 5) {
+            if (pick == 5 && p->m512_62 != 2) {
                 p->m512_62 = m5 && !strcmp(m5, "62");     // 384-voxel 6x2x32 tile: measured behind the 4x2x32 kernel, opt-in
                 p->BM = p->m512_62 ? 384 : 512;
             }
@@ -779,7 +788,9 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
-    if (p->halo3 == 5) {
+    if (p->halo3 == 5 && p->m512_62 == 2) {
+        p->TD = 4; p->TH = 8; p->TW = 16;
+    } else if (p->halo3 == 5) {
         p->TD = p->m512_62 ? 6 : 4; p->TH = p->m512_62 ? 2 : 4; p->TW = 32;
     } else if (p->halo3 >= 2) {
         p->TD = 4; p->TH = 2; p->TW = 32;

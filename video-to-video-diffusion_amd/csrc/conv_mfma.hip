@@ -1032,7 +1032,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
     memcpy(k.ad_min, p->ad_min, sizeof(k.ad_min));
     int mode = p->small ? 1 : (p->fast ? 2 : 0);
     {   // deep-ring variant for launches that cannot hide DMA latency behind other blocks of the same CU
-        static const char* ring = getenv("CTSI_CONV_RING");   // "0" | "1" (tuning aid)
+        const char* ring = getenv("CTSI_CONV_RING");   // "0" | "1" (tuning aid; read per launch)
         const bool small_grid = grid <= 256 && !(p->BM == 256 && p->BN == 256);   // at most one block per CU: the ring's
                                                                                    // 128-144 KB of LDS evict no second block
         if (mode == 2 && ((small_grid && !(ring && !strcmp(ring, "0"))) || (ring && !strcmp(ring, "1")))) mode = 3;

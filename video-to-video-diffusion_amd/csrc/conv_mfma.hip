@@ -40,6 +40,7 @@ struct ConvKParams {
     int Dr, Hr, Wr;
     int sH, sW;
     int lTH, lTW;
+    int linear;   // 1: a tile = BM consecutive voxels of the (d, h, w) row grid (no power-of-two box, no padded rows)
     int tilesD, tilesH, tilesW, tps, mtiles;
     int ntiles_n;
     int T, ksteps, kc_per_tap, lcpt;  // kc_per_tap: 64-chunks per tap (big mode); lcpt: log2(chunks per tap) small
@@ -109,19 +110,43 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     const int n0 = nt * BN;
     const int nb = mt / p.tps;
     int r0 = mt - nb * p.tps;
-    const int tD = r0 / (p.tilesH * p.tilesW);
-    r0 -= tD * p.tilesH * p.tilesW;
-    const int tH = r0 / p.tilesW;
-    const int tW = r0 - tH * p.tilesW;
     const int TWm = (1 << p.lTW) - 1, THm = (1 << p.lTH) - 1;
     const int lTHW = p.lTH + p.lTW;
-    const int d0 = tD * (BM >> lTHW), h0 = tH << p.lTH, w0 = tW << p.lTW;
+    int d0, h0 = 0, w0 = 0;
+    const int HWr = p.Hr * p.Wr;
+    if (p.linear) {          // small planes (6x6, 12x12, ...): box tiles would be mostly padding
+        d0 = (r0 * BM) / HWr;
+    } else {
+        const int tD = r0 / (p.tilesH * p.tilesW);
+        r0 -= tD * p.tilesH * p.tilesW;
+        const int tH = r0 / p.tilesW;
+        const int tW = r0 - tH * p.tilesW;
+        d0 = tD * (BM >> lTHW);
+        h0 = tH << p.lTH;
+        w0 = tW << p.lTW;
+    }
+    const int vlin0 = r0 * BM;   // linear mode: first voxel of the tile inside the sample
+    // row r of the tile -> (d, h, w) of the row grid
+    auto row_dhw = [&](int r, int& d, int& h, int& w) {
+        if (p.linear) {
+            const int v = vlin0 + r;
+            d = v / HWr;
+            const int rem = v - d * HWr;
+            h = rem / p.Wr;
+            w = rem - h * p.Wr;
+        } else {
+            d = d0 + (r >> lTHW);
+            h = h0 + ((r >> p.lTW) & THm);
+            w = w0 + (r & TWm);
+        }
+    };
     const int tapbase = cls * p.T;
 
     // ---- per-row bookkeeping ----------------------------------------------------------------
     if (tid < BM) {
         const int r = tid;
-        const int d = d0 + (r >> lTHW), h = h0 + ((r >> p.lTW) & THm), w = w0 + (r & TWm);
+        int d, h, w;
+        row_dhw(r, d, h, w);
         long long off = -1;
         if (d < p.Dr && h < p.Hr && w < p.Wr) {
             const int ho = h * p.uH + p.pH[cls], wo = w * p.uW + p.pW[cls];
@@ -151,7 +176,8 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         const int j = wave * A_INSTR + i;
         const int r = j * 8 + (lane >> 3);
         a_q8[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-        const int d = d0 + (r >> lTHW), h = h0 + ((r >> p.lTW) & THm), w = w0 + (r & TWm);
+        int d, h, w;
+        row_dhw(r, d, h, w);
         const bool rv = (d < p.Dr) && (h < p.Hr) && (w < p.Wr);
         const int hi = h * p.sH, wi = w * p.sW;
         a_iv0[i] = ((nb * p.Di + d + p.dshift) * p.Hi + hi) * p.Wi + wi;
@@ -542,6 +568,7 @@ struct ctsi_conv_plan {
     int small, lcpt, kc_per_tap, ksteps, Ktot;
     int BM, BN, CoutPad, ntiles_n;
     int lTH, lTW, TD, TH, TW, tilesD, tilesH, tilesW, tps, mtiles;
+    int linear;   // gather kernel: tiles are runs of BM consecutive row-grid voxels
     int tapk[CTSI_MAX_TAPS];
     int tapdelta[CTSI_MAX_TAPS];
     int8_t od[CTSI_MAX_TAPS], oh[CTSI_MAX_TAPS], ow[CTSI_MAX_TAPS];
@@ -814,6 +841,18 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     p->tilesH = ceil_div(p->Hr, p->TH);
     p->tilesW = ceil_div(p->Wr, p->TW);
     p->tps = p->tilesD * p->tilesH * p->tilesW;
+    if (!p->halo3) {
+        // gather kernel on small planes: a power-of-two box tile over e.g. a 6 x 6 plane is 44 % padding rows; runs of
+        // BM consecutive voxels have none (only the last tile of a sample is ragged)
+        const long long rows = (long long)p->Dr * p->Hr * p->Wr;
+        const long long boxed = (long long)p->tps * p->BM;
+        const char* lin = getenv("CTSI_CONV_LINEAR");   // "0" | "1" (tuning aid)
+        if ((boxed * 100 > rows * 115 && !(lin && !strcmp(lin, "0"))) || (lin && !strcmp(lin, "1"))) {
+            p->linear = 1;
+            p->tps = (int)((rows + p->BM - 1) / p->BM);
+            p->TD = (int)(p->BM / ((long long)p->Hr * p->Wr)) + 2;   // depth slices one tile can touch (fast-path extent)
+        }
+    }
     p->mtiles = d.n * p->tps;
     {   // buffer-addressed fast path: whole 64-channel chunks per source and a tile halo that fits 2^31 bytes
         const int cmax = d.c1 > d.c2 ? d.c1 : d.c2;
@@ -1005,6 +1044,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
     k.Dr = p->Dr; k.Hr = p->Hr; k.Wr = p->Wr;
     k.sH = p->sH; k.sW = p->sW;
     k.lTH = p->lTH; k.lTW = p->lTW;
+    k.linear = p->linear;
     k.tilesD = p->tilesD; k.tilesH = p->tilesH; k.tilesW = p->tilesW; k.tps = p->tps; k.mtiles = p->mtiles;
     k.ntiles_n = p->ntiles_n;
     k.T = p->T; k.ksteps = p->ksteps; k.kc_per_tap = p->kc_per_tap; k.lcpt = p->lcpt;

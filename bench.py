@@ -246,6 +246,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU, RCCL) before
+        # this process has touched the GPU, and exit with the launcher's code.  (Never exec: a process that has
+        # initialised HIP must not be replaced.)
+        import socket
+        import subprocess
+        ngpu = torch.cuda.device_count()
+        if ngpu < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} requested but only {ngpu} GPU(s) are visible")
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None

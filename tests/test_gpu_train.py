@@ -132,6 +132,44 @@ def test_optimizer_loop_and_accumulation(pkg):
     assert la.item() == lb.item()
 
 
+def test_stale_tape_is_refused_and_weight_writes_are_seen(pkg):
+    """(1) A second forward of the same shape overwrites the program's saved activations: the first loss's backward must
+    raise instead of silently differentiating through the wrong batch.  (2) Weight changes the engine must notice
+    without being told: in-place optimizer-style writes, load_state_dict, a replaced Parameter; and the one it cannot
+    (p.data writes) after invalidate_engine_cache()."""
+    model, sd, cfg = tiny_model_sd(pkg)
+    model.to(DEV)
+    v_in, v_gt, noise = (x.to(DEV) for x in _inputs())
+    t = T_FIX.to(DEV)
+    l1, _ = model(v_in, v_gt, t=t, noise=noise)
+    l2, _ = model(v_in.flip(0), v_gt.flip(0), t=t, noise=noise)
+    with pytest.raises(pkg.CtsiError, match="saved activations were overwritten"):
+        (l1 + l2).backward()
+    l3, _ = model(v_in, v_gt, t=t, noise=noise)       # a fresh forward/backward pair still works
+    l3.backward()
+    # inference between a training forward and its backward does not touch the tape
+    l4, _ = model(v_in, v_gt, t=t, noise=noise)
+    with torch.no_grad():
+        model.unet(noise, t, noise)
+    l4.backward()
+    base = float(l4)
+    w = model.unet.conv_in.weight
+    with torch.no_grad():
+        w.mul_(1.5)                                     # version bump
+    la = float(model(v_in, v_gt, t=t, noise=noise)[0])
+    assert abs(la - base) > 1e-6 * abs(base)
+    model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
+    assert abs(float(model(v_in, v_gt, t=t, noise=noise)[0]) - base) <= 1e-6 * abs(base)
+    model.unet.conv_in.weight = torch.nn.Parameter(w.detach() * 1.5)      # replaced object: rebuild + new grads target
+    lb, _ = model(v_in, v_gt, t=t, noise=noise)
+    assert abs(float(lb) - la) <= 1e-6 * abs(la)
+    lb.backward()
+    assert model.unet.conv_in.weight.grad is not None
+    model.unet.conv_in.weight.data.copy_(sd["unet.conv_in.weight"])       # invisible to torch's version counters
+    model.invalidate_engine_cache()
+    assert abs(float(model(v_in, v_gt, t=t, noise=noise)[0]) - base) <= 1e-6 * abs(base)
+
+
 def test_training_loss_latent4_three_levels(pkg):
     """The 163 M-variant's shape family (latent_dim 4 -> 8-channel padded input / output-gradient tensors, 3 levels,
     attention at two levels, 8 heads, odd spatial sizes at the coarsest level) straight through

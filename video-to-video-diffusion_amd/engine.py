@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -63,9 +64,11 @@ class Ctx:
     def scope(self):
         """Run a block on the engine stream, ordered after/before the caller's current stream."""
         self.enter()
-        with torch.cuda.stream(self.stream):
-            yield self
-        self.leave()
+        try:
+            with torch.cuda.stream(self.stream):
+                yield self
+        finally:   # also on an exception: the caller's stream must still wait for what was queued
+            self.leave()
 
 
 class _Pool:
@@ -206,15 +209,34 @@ class Program:
         self.pack_fns.append(refresh)
         return buf
 
+    def _fingerprint(self):
+        """What the packed weights were made from: the tracked Parameter objects' in-place version counters and
+        storage addresses, plus (when the program knows its module) the objects and addresses the module's
+        parameter names resolve to NOW -- so optimizer steps, `load_state_dict` (in place or assign=True) and a
+        replaced `module.weight` are all seen.  Writes through `p.data` / raw pointers bump nothing torch can
+        observe: call `model.invalidate_engine_cache()` after those."""
+        fp = [(p._version, p.data_ptr()) for p in self._params]
+        mod = getattr(self, "_track_module", None)
+        if mod is not None:
+            fp.extend((id(p), p._version, p.data_ptr()) for p in mod.parameters())
+        return tuple(fp)
+
+    def track_module(self, module: nn.Module):
+        self._track_module = module
+        self.track(*list(module.parameters()))
+
     def repack(self):
         with torch.cuda.stream(self.ctx.stream):
             for fn in self.pack_fns:
                 fn()
-        self._versions = tuple(p._version for p in self._params)
+        self._versions = self._fingerprint()
 
     def ensure_fresh(self):
-        if tuple(p._version for p in self._params) != self._versions:
+        if self._fingerprint() != self._versions:
             self.repack()
+
+    def needs_rebuild(self) -> bool:
+        return False
 
     # ---- conv ----------------------------------------------------------------------------------------------
     def conv(self, name: str, weight_fn, bias_fn, x1: Act, x2: Optional[Act], *, transposed=False,
@@ -569,7 +591,7 @@ class UNetProgram(Program):
         self.t_rows = self.persistent((max_rows,), torch.int32, zero=True)
         self.coef = self.persistent((max_rows, 8), torch.float32, zero=True)
         self.noise = None  # fp32 NCDHW, allocated on demand
-        self.track(*[p for p in unet.parameters()])
+        self.track_module(unet)
 
         # ---- time embedding: stack every ResBlock's Linear(time_dim -> cout) -------------------------
         te = unet.time_embed.time_mlp
@@ -737,7 +759,7 @@ class VAEEncodeProgram(Program):
         self.n, self.d, self.h, self.w = n, d, h, w
         cin = vae.in_channels
         self.cin, self.cin_pad = cin, _pad8(cin)
-        self.track(*[p for p in enc.parameters()])
+        self.track_module(enc)
         self.xin = Act(self.persistent((n * d * h * w * self.cin_pad,), torch.bfloat16, zero=True), n,
                        self.cin_pad, d, h, w)
         self.zero_gn_op()
@@ -817,7 +839,7 @@ class VAEDecodeProgram(VAEEncodeProgram):
         self.n, self.d, self.h, self.w = n, d, h, w
         L = vae.latent_dim
         self.L, self.L_pad = L, _pad8(L)
-        self.track(*[p for p in dec.parameters()])
+        self.track_module(dec)
         halo = 0 if shard is None else 1
         self.zin = Act(self.persistent((n * (d + 2 * halo) * h * w * self.L_pad,), torch.bfloat16, zero=True), n,
                        self.L_pad, d, h, w, halo)
@@ -865,11 +887,27 @@ class VAEDecodeProgram(VAEEncodeProgram):
 # ==========================================================================================================
 # program caches hung off the modules
 # ==========================================================================================================
+PROGRAM_CACHE_SIZE = int(os.environ.get("CTSI_PROGRAM_CACHE", "4"))   # programs kept per module (they own their
+                                                                        # activation buffers: ~5 GB for the 512^2 U-Net)
+
+
+def invalidate_engine_cache(module: nn.Module):
+    """Drop every cached program (packed weights, captured graphs, activation buffers) of `module` and its
+    sub-modules; the next call rebuilds from the current parameters."""
+    for m in module.modules():
+        m.__dict__.pop("_ctsi_programs", None)
+
+
 def cached_program(module: nn.Module, key, build: Callable[[], Program]) -> Program:
     cache = module.__dict__.setdefault("_ctsi_programs", {})
     prog = cache.get(key)
+    if prog is not None and prog.needs_rebuild():
+        cache.pop(key)
+        prog = None
+    if prog is not None:
+        cache[key] = cache.pop(key)   # LRU: most recently used last
     if prog is None:
-        if len(cache) >= 4:  # programs own large activation buffers: keep a handful per module
+        if len(cache) >= max(1, PROGRAM_CACHE_SIZE):
             cache.pop(next(iter(cache)))
         prog = build()
         cache[key] = prog

@@ -64,6 +64,13 @@ class VideoToVideoDiffusion(nn.Module):
         self.config = config
         self.use_pretrained = use_pretrained
 
+    def invalidate_engine_cache(self):
+        """Drop the engine's cached programs (packed bf16 weights, captured graphs) -- needed only after weight
+        writes torch cannot observe (`p.data[...] = ...`, raw-pointer copies); optimizer steps, `load_state_dict`
+        and replaced parameters are detected automatically (engine.Program._fingerprint)."""
+        from .engine import invalidate_engine_cache
+        invalidate_engine_cache(self)
+
     def encode_videos(self, v_in, v_gt=None):
         z_in = self.vae.encode(v_in)
         if v_gt is not None:

@@ -164,9 +164,9 @@ class DDPMSampler:
     @torch.no_grad()
     def sample_with_stitching(self, v_thick_full, vae, patch_size=(8, 192, 192),
                               target_patch_size=(48, 192, 192), stride=(4, 96, 96), device='cuda',
-                              progress=True):
+                              progress=True, dp_group=None):
         return _stitched(self, v_thick_full, vae, patch_size, target_patch_size, stride, device, progress,
-                         lambda shp, cond: self.sample(shp, cond, device, progress=False))
+                         lambda shp, cond: self.sample(shp, cond, device, progress=False), dp_group=dp_group)
 
     def _create_gaussian_weight(self, d, h, w):
         return gaussian_weight(d, h, w)
@@ -199,8 +199,11 @@ class DDIMSampler:
     @torch.no_grad()
     def sample_with_stitching(self, v_thick_full, vae, num_inference_steps=20, patch_size=(8, 192, 192),
                               target_patch_size=(48, 192, 192), stride=(4, 96, 96), device='cuda', eta=0.0,
-                              progress=True, window_batch=8):
-        """`window_batch` (additive kwarg): windows are independent, so for the deterministic sampler (eta == 0) up to
+                              progress=True, window_batch=8, dp_group=None):
+        """`dp_group` (additive kwarg, default None = every window on this process, as in the reference): a
+        torch.distributed process group (or True for the default group) over which the windows are split; every rank
+        of the group must make the call with the SAME volume.
+        `window_batch` (additive kwarg): windows are independent, so for the deterministic sampler (eta == 0) up to
         that many are encoded / sampled / decoded as one batch -- a single 192x192 patch leaves most of an MI355X
         idle (its coarsest level has 28 conv tiles for 256 CUs).  The initial noise of every window is still drawn
         with its own `torch.randn` call in window order, exactly as the reference's one-by-one loop draws it."""
@@ -211,7 +214,7 @@ class DDIMSampler:
         return _stitched(self, v_thick_full, vae, patch_size, target_patch_size, stride, device, progress,
                          lambda shp, cond: self.sample(shp, cond, num_inference_steps, device, eta=eta,
                                                        progress=False),
-                         batched_fn=batched, window_batch=window_batch)
+                         batched_fn=batched, window_batch=window_batch, dp_group=dp_group)
 
     def _create_gaussian_weight(self, d, h, w):
         return gaussian_weight(d, h, w)
@@ -231,8 +234,26 @@ def _axis_window(n: int) -> torch.Tensor:
     return torch.exp(-(x ** 2) / (2 * (n / 6) ** 2))
 
 
+def _window_partition(windows, dp_group, sampler):
+    """Which windows this process computes: all of them unless `dp_group` opts in to window data parallelism.
+    Returns (my_windows, world, group)."""
+    rank, world, group = 0, 1, None
+    if dp_group is not None and dp_group is not False:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise CtsiError("sample_with_stitching(dp_group=...) needs an initialised torch.distributed process group")
+        comm = getattr(getattr(sampler, "model", None), "depth_shard_comm", None)
+        if comm is not None and getattr(comm, "world", 1) > 1:
+            raise CtsiError("window data parallelism (dp_group=) cannot be combined with depth sharding "
+                            "(unet.depth_shard_comm): depth-sharded ranks must all run the same window")
+        group = None if dp_group is True else dp_group
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    from .parallel import shard_units
+    return [windows[i] for i in shard_units(len(windows), rank, world)], world, group
+
+
 def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride, device, progress, sample_fn,
-              batched_fn=None, window_batch=1):
+              batched_fn=None, window_batch=1, dp_group=None):
     """Sliding-window inference (sampler.py:63-172, 338-453): per window encode -> sample -> decode on the
     engine, Gaussian-weighted accumulation (ctsi_blend_accumulate) and final normalisation
     (ctsi_blend_normalize) on device.
@@ -243,8 +264,12 @@ def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride,
     conditioning latent is upsampled along depth to the target depth first, exactly as
     VideoToVideoDiffusion.generate does for a whole volume (models/model.py:284-289), so every window
     produces a (target_d, h, w) patch that lands at depth int(d_start * depth_ratio).
-    Under torch.distributed the windows are data-parallel units (parallel.shard_units): every rank blends
-    its share and the accumulators are all-reduced before normalisation."""
+    Window data parallelism is OPT-IN (`dp_group=`): by default every window is computed by the calling process,
+    whatever the state of torch.distributed -- the reference's behaviour, and the only safe one when ranks validate
+    different volumes or only rank 0 calls.  With `dp_group` (a process group, or True for the default group) the
+    windows are data-parallel units (parallel.shard_units): every rank of the group must call with the same volume,
+    blends its share, and the accumulators are all-reduced over that group before normalisation.  It cannot be
+    combined with depth sharding (`unet.depth_shard_comm`): there every rank must run the same window."""
     b, c, d_thick, hf, wf = v_thick_full.shape
     pd, ph, pw = patch_size
     td, th, tw = target_patch_size
@@ -261,15 +286,7 @@ def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride,
     wd, wh, ww = (_axis_window(n).to(ctx.device) for n in (td, th, tw))
     windows = [(ds, hs, ws) for ds in _window_starts(d_thick, pd, stride[0])
                for hs in _window_starts(hf, ph, stride[1]) for ws in _window_starts(wf, pw, stride[2])]
-    rank, world = 0, 1
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            rank, world = dist.get_rank(), dist.get_world_size()
-    except Exception:  # pragma: no cover
-        dist = None
-    from .parallel import shard_units
-    mine = [windows[i] for i in shard_units(len(windows), rank, world)]
+    mine, world, pg = _window_partition(windows, dp_group, sampler)
     it = None
     if progress and tqdm is not None:
         it = tqdm(desc="Patch-based inference", total=len(mine))
@@ -302,8 +319,9 @@ def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride,
     if it is not None:
         it.close()
     if world > 1:
-        dist.all_reduce(acc)
-        dist.all_reduce(wsum)
+        import torch.distributed as dist
+        dist.all_reduce(acc, group=pg)
+        dist.all_reduce(wsum, group=pg)
     with ctx.scope():
         lib.blend_normalize(_ptr(acc), _ptr(wsum), acc.numel(), sptr)
     return acc

@@ -46,7 +46,7 @@ class UNetTrainProgram(Program):
         self._need = dict(wgrad=16, gn=16, chsum=16)
         self._ws: Dict[str, Optional[torch.Tensor]] = dict(wgrad=None, gn=None, chsum=None)
         self.params = [p for p in unet.parameters()]
-        self.track(*self.params)
+        self.track_module(unet)
         for p in self.params:
             if not p.is_cuda:
                 raise CtsiError("training runs on the HIP engine: move the model to a ROCm device first")
@@ -141,6 +141,7 @@ class UNetTrainProgram(Program):
 
         self._emit(run_loss, "loss.fwd")
         self.n_fwd = len(self.ops)
+        self.generation = 0   # bumped by every run_forward (see there)
 
         # ---- backward: loss, then the tape in reverse, then the time embedding ---------------------------------
         def run_loss_bwd():
@@ -479,13 +480,23 @@ class UNetTrainProgram(Program):
             self.grads[id(m.time_mlp[1].weight)] = self.g_w_all[off:off + co]
             self.grads[id(m.time_mlp[1].bias)] = self.g_b_all[off:off + co]
 
+    def needs_rebuild(self) -> bool:
+        """The autograd bridge hands gradients to the Parameter objects captured at build time: a replaced
+        parameter (load_state_dict(assign=True), module.weight = ...) needs a new program, not just a repack."""
+        cur = list(self.unet.parameters())
+        return len(cur) != len(self.params) or any(a is not b for a, b in zip(cur, self.params))
+
     # ---- execution ---------------------------------------------------------------------------------------------------------
     def set_diffusion(self, diffusion):
         self.sqrt_ac = diffusion.sqrt_alphas_cumprod.detach().to(self.ctx.device, torch.float32).contiguous()
         self.sqrt_1mac = diffusion.sqrt_one_minus_alphas_cumprod.detach().to(self.ctx.device, torch.float32).contiguous()
 
     def run_forward(self, z0, cond, t, noise, norm, mask=None) -> torch.Tensor:
+        """Runs the forward launches and overwrites the tape (saved activations, t, noise) of this program: the
+        generation counter lets a backward that belongs to an EARLIER forward of the same shape fail loudly instead of
+        differentiating through the wrong activations (l1 = model(a); l2 = model(b); (l1 + l2).backward())."""
         self.ensure_fresh()
+        self.generation += 1
         self.z0.copy_(z0)
         self.cond.copy_(cond)
         self.noise.copy_(noise)
@@ -498,7 +509,13 @@ class UNetTrainProgram(Program):
             op()
         return self.loss_out[0].clone()
 
-    def run_backward(self, grad_out: torch.Tensor) -> List[torch.Tensor]:
+    def run_backward(self, grad_out: torch.Tensor, generation: Optional[int] = None) -> List[torch.Tensor]:
+        if generation is not None and generation != self.generation:
+            raise CtsiError(
+                "backward of a training forward whose saved activations were overwritten: another forward of the same "
+                f"shape ran on this program in between (tape generation {generation}, now {self.generation}).  Call "
+                "backward() before the next forward of that shape, or evaluate the second batch under torch.no_grad() "
+                "through model.generate / unet(x, t, c), which do not touch the training tape.")
         self.gscale.copy_(grad_out.reshape(1).to(torch.float32))
         for op in self.ops[self.n_fwd:]:
             op()
@@ -521,13 +538,14 @@ class _TrainStep(torch.autograd.Function):
         with ectx.scope():
             loss = prog.run_forward(z0, cond, t, noise, norm, mask)
         fctx.prog = prog
+        fctx.generation = prog.generation
         return loss
 
     @staticmethod
     def backward(fctx, grad_out):
         prog = fctx.prog
         with prog.ctx.scope():
-            grads = prog.run_backward(grad_out)
+            grads = prog.run_backward(grad_out, fctx.generation)
             grads = [g.clone() for g in grads]
         return (None,) * 7 + tuple(grads)
 

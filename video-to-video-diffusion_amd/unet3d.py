@@ -165,6 +165,13 @@ class UNet3D(nn.Module):
         return _largest_group_count(channels)
 
     # ---- engine plumbing ---------------------------------------------------------------------------
+    def invalidate_engine_cache(self):
+        """Drop the engine's cached programs (packed bf16 weights, captured graphs) -- needed only after weight
+        writes torch cannot observe (`p.data[...] = ...`, raw-pointer copies); optimizer steps, `load_state_dict`
+        and replaced parameters are detected automatically (engine.Program._fingerprint)."""
+        from .engine import invalidate_engine_cache
+        invalidate_engine_cache(self)
+
     def program(self, ctx: Ctx, n: int, d: int, h: int, w: int, max_rows: int) -> UNetProgram:
         key = ("unet", ctx.device.index, n, d, h, w, max_rows, self.attention_mode)
         return cached_program(self, key, lambda: UNetProgram(ctx, self, n, d, h, w, max_rows,

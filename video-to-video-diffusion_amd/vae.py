@@ -96,6 +96,13 @@ class SliceInterpolationVAE(nn.Module):
         self.decoder = VideoDecoder(latent_dim, in_channels, base_channels)
         self.scaling_factor = scaling_factor
 
+    def invalidate_engine_cache(self):
+        """Drop the engine's cached programs (packed bf16 weights, captured graphs) -- needed only after weight
+        writes torch cannot observe (`p.data[...] = ...`, raw-pointer copies); optimizer steps, `load_state_dict`
+        and replaced parameters are detected automatically (engine.Program._fingerprint)."""
+        from .engine import invalidate_engine_cache
+        invalidate_engine_cache(self)
+
     def _check(self, t: torch.Tensor, what: str):
         if not t.is_cuda:
             raise CtsiError(f"SliceInterpolationVAE.{what} runs on the HIP engine: move the tensor to a ROCm "

@@ -234,7 +234,7 @@ def ddim_sample(model: Callable, buffers: SD, shape, cond, n_steps: int, eta: fl
     z = _guard(z)
     b = shape[0]
     for i, t_idx in enumerate(ts):
-        t = torch.full((b,), int(t_idx), dtype=torch.long)
+        t = torch.full((b,), int(t_idx), dtype=torch.long, device=z.device)
         eps = _guard(model(z, t, cond))
         a = ac[int(t_idx)]
         a_prev = ac[int(ts[i + 1])] if i < len(ts) - 1 else torch.tensor(1.0)
@@ -260,7 +260,7 @@ def ddpm_sample(model: Callable, buffers: SD, shape, cond, noise_fn: Optional[Ca
     b = shape[0]
     z = noise_fn(-1, tuple(shape)) if noise_fn else torch.randn(shape)
     for i, t_idx in enumerate(list(reversed(range(total)))[:num_steps]):
-        t = torch.full((b,), t_idx, dtype=torch.long)
+        t = torch.full((b,), t_idx, dtype=torch.long, device=z.device)
         eps = model(z, t, cond)
         ex = lambda name: buffers[name][t_idx].float()
         z0 = (z - ex("sqrt_one_minus_alphas_cumprod") * eps) / ex("sqrt_alphas_cumprod")

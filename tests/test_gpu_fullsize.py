@@ -1,0 +1,272 @@
+"""GPU: parity at the sizes bench.py actually measures (BASELINE.json configs 1-3), production widths.
+
+Oracle = oracle.ref_ops (fp32 restatement of the reference, pinned by tests/golden) evaluated with torch on the
+same device in fp32; the engine computes in bf16 storage / fp32 accumulation.  Tolerances, as everywhere:
+  single conv        rel-L2 <= 3e-3 vs F.conv3d on the same bf16-rounded operands (fp32 accumulate, bf16 output)
+  whole networks     rel-L2 <= 3e-2 vs the fp32 oracle (PyTorch's own bf16 autocast of the reference: 2.3-2.6e-2)
+  sampling pipeline  PSNR(hip, oracle fp32) >= PSNR(oracle under bf16 autocast, oracle fp32) - 0.1 dB
+  training           loss within 2 %; per-tensor gradient rel-L2 <= 2 x (oracle under bf16 autocast) + 2e-2
+"""
+import importlib
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_ops as R
+from tests.helpers import bf16_round, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NET_TOL = 3e-2
+CONV_TOL = 3e-3
+UNET_CFG = dict(model_channels=128, num_res_blocks=2, attention_levels=[1, 2], channel_mult=[1, 2, 4, 4], num_heads=4,
+                scaling_factor=1.0)
+FULL_CFG = {'model': {'in_channels': 1, 'latent_dim': 8, 'vae_base_channels': 128, 'vae_scaling_factor': 1.0},
+            'pretrained': {'use_pretrained': True, 'vae': {'enabled': True, 'checkpoint_path': 'unused'}},
+            'noise_schedule': 'cosine', 'diffusion_timesteps': 1000}
+
+
+def _randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def _free():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture(scope="module")
+def G():
+    from tests import gpu_utils
+    return gpu_utils
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# (b) the dominant kernel on the real layer shapes of the config-2 step (3072 / 1536 / 768-block grids through the XCD
+#     remap), including the GroupNorm column sums its epilogue emits
+# --------------------------------------------------------------------------------------------------------------------
+REAL_SHAPES = [
+    ("L0_128_128_48x128x128", 128, 0, 128, (1, 48, 128, 128)),      # conv3_halo32m<4,4,32>: 20 launches per step
+    ("L0_concat_256+128_to_128", 256, 128, 128, (1, 48, 128, 128)),  # decoder level 3, first block (two sources)
+    ("L1_256_256_48x64x64", 256, 0, 256, (1, 48, 64, 64)),
+    ("L2_512_512_48x32x32", 512, 0, 512, (1, 48, 32, 32)),           # conv3_halo32 (4x2x32 tile)
+    ("L3_512_512_48x16x16", 512, 0, 512, (1, 48, 16, 16)),           # 16-wide level
+]
+
+
+@pytest.mark.parametrize("name,c1,c2,cout,dims", REAL_SHAPES, ids=[c[0] for c in REAL_SHAPES])
+def test_halo_conv_on_benchmarked_layer_shapes(G, name, c1, c2, cout, dims):
+    n, d, h, w = dims
+    cin = c1 + c2
+    x1 = bf16_round(_randn((n, c1, d, h, w), 1))
+    x2 = bf16_round(_randn((n, c2, d, h, w), 2)) if c2 else None
+    wt = bf16_round(_randn((cout, cin, 3, 3, 3), 3) * (1.5 / math.sqrt(cin * 27)))
+    b = _randn((cout,), 4) * 0.1
+    groups = 32
+    y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=groups)
+    x = (torch.cat([x1, x2], 1) if c2 else x1).to(DEV)
+    ref = F.conv3d(x, wt.to(DEV), b.to(DEV), padding=1)
+    del x
+    assert tuple(y.shape) == tuple(ref.shape)
+    yd = y.to(DEV)
+    e = rel_l2(yd, ref)
+    amax = float((yd - ref).abs().max()) / float(ref.abs().max())
+    print(f"{name}: rel-L2 {e:.3g}, max|d|/max|ref| {amax:.3g}")
+    assert e < CONV_TOL and amax < 2e-2
+    rg = ref.reshape(n, groups, -1).double()
+    s_ref, q_ref = rg.sum(-1).cpu(), (rg * rg).sum(-1).cpu()
+    assert torch.allclose(sums[..., 0], s_ref, rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+    assert torch.allclose(sums[..., 1], q_ref, rtol=2e-3)
+    del ref, yd, rg
+    _free()
+
+
+def test_gather_conv_on_benchmarked_layer_shapes(G):
+    """The non-3x3x3 layers of the config-2 step at their real sizes: strided (3,4,4) down-conv 128->128 from 128^2,
+    ConvTranspose (3,4,4) 256->256 to 128^2, the 1x1x1 residual conv 384->128, and the 128->8 fp32 head."""
+    x = bf16_round(_randn((1, 128, 48, 128, 128), 5))
+    wt = bf16_round(_randn((128, 128, 3, 4, 4), 6) * (1.5 / math.sqrt(128 * 48)))
+    b = _randn((128,), 7) * 0.1
+    y, _ = G.run_conv(x, None, wt, b, k=(3, 4, 4), s=(2, 2))
+    ref = F.conv3d(x.to(DEV), wt.to(DEV), b.to(DEV), stride=(1, 2, 2), padding=(1, 1, 1))
+    assert rel_l2(y.to(DEV), ref) < CONV_TOL
+    # 128 -> 8 head, fp32 strided output
+    wh = bf16_round(_randn((8, 128, 3, 3, 3), 8) * (1.5 / math.sqrt(128 * 27)))
+    bh = _randn((8,), 9) * 0.1
+    yh, _ = G.run_conv(x, None, wh, bh, f32=True)
+    refh = F.conv3d(x.to(DEV), wh.to(DEV), bh.to(DEV), padding=1)
+    assert rel_l2(yh.to(DEV), refh) < 1e-3      # fp32 output: no bf16 rounding of the result
+    del ref, refh
+    _free()
+    x2 = bf16_round(_randn((1, 256, 48, 64, 64), 10))
+    wt2 = bf16_round(_randn((256, 256, 3, 4, 4), 11) * (1.5 / math.sqrt(256 * 12)))
+    b2 = _randn((256,), 12) * 0.1
+    y2, sums = G.run_conv(x2, None, wt2, b2, transposed=True, k=(3, 4, 4), s=(2, 2), want_stats=True, groups=32)
+    ref2 = F.conv_transpose3d(x2.to(DEV), wt2.to(DEV), b2.to(DEV), stride=(1, 2, 2), padding=(1, 1, 1))
+    assert tuple(y2.shape) == (1, 256, 48, 128, 128)
+    assert rel_l2(y2.to(DEV), ref2) < CONV_TOL
+    rg = ref2.reshape(1, 32, -1).double()
+    assert torch.allclose(sums[..., 0], rg.sum(-1).cpu(), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+    assert torch.allclose(sums[..., 1], (rg * rg).sum(-1).cpu(), rtol=2e-3)
+    del ref2, rg
+    _free()
+    xa, xb = bf16_round(_randn((1, 256, 48, 128, 128), 13)), x
+    w1 = bf16_round(_randn((128, 384, 1, 1, 1), 14) * (1.5 / math.sqrt(384)))
+    y1, _ = G.run_conv(xa, xb, w1, b, k=(1, 1, 1), p=(0, 0, 0))
+    ref1 = F.conv3d(torch.cat([xa, xb], 1).to(DEV), w1.to(DEV), b.to(DEV))
+    assert rel_l2(y1.to(DEV), ref1) < CONV_TOL
+    del ref1
+    _free()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# (a) the benchmarked U-Net evaluation: effective 264.66 M-param model at latent (1, 8, 48, 128, 128)
+# --------------------------------------------------------------------------------------------------------------------
+def test_unet_at_config2_latent(pkg):
+    torch.manual_seed(0)
+    un = pkg.UNet3D(latent_dim=8).eval().to(DEV)
+    sd = {k: v.detach() for k, v in un.state_dict().items()}
+    x, c = _randn((1, 8, 48, 128, 128), 1).to(DEV), _randn((1, 8, 48, 128, 128), 2).to(DEV)
+    for tv in (500, 999):
+        t = torch.tensor([tv], device=DEV)
+        out = un(x, t, c)
+        with torch.no_grad():
+            ref = R.unet_forward(sd, UNET_CFG, x, t, c)
+        e = rel_l2(out, ref)
+        print(f"U-Net (1,8,48,128,128) t={tv}: rel-L2 vs fp32 oracle {e:.3g}")
+        assert torch.isfinite(out).all() and e < NET_TOL
+        del ref
+    # the captured-graph sampler step computes the same epsilon as the plain forward (same kernels, same order)
+    un.invalidate_engine_cache()
+    _free()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# (c) the production VAE (base 128: 128/256/512 channels) at the config-1 and config-2 sizes
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def prod_vae(pkg):
+    torch.manual_seed(0)
+    vae = pkg.VideoVAE(in_channels=1, latent_dim=8, base_channels=128, scaling_factor=1.0).eval().to(DEV)
+    sd = {k: v.detach() for k, v in vae.state_dict().items()}
+    yield vae, sd
+    vae.invalidate_engine_cache()
+    _free()
+
+
+@pytest.mark.parametrize("hw", [192, 512])
+def test_production_vae_encode(prod_vae, hw):
+    vae, sd = prod_vae
+    v = (torch.rand((1, 1, 8, hw, hw), generator=torch.Generator().manual_seed(3)) * 2 - 1).to(DEV)
+    z = vae.encode(v)
+    with torch.no_grad():
+        ref = R.vae_encode(sd, v, 1.0)
+    e = rel_l2(z, ref)
+    print(f"VAE encode (1,1,8,{hw},{hw}) -> {tuple(z.shape)}: rel-L2 {e:.3g}")
+    assert tuple(z.shape) == (1, 8, 8, hw // 4, hw // 4) and e < NET_TOL
+    del ref
+    vae.invalidate_engine_cache()
+    _free()
+
+
+@pytest.mark.parametrize("hl", [48, 128])
+def test_production_vae_decode(prod_vae, hl):
+    vae, sd = prod_vae
+    z = _randn((1, 8, 48, hl, hl), 4).to(DEV)
+    out = vae.decode(z)
+    with torch.no_grad():
+        ref = R.vae_decode(sd, z, 1.0)
+    e = rel_l2(out, ref)
+    p = R.psnr(out, ref, 2.0)
+    print(f"VAE decode (1,8,48,{hl},{hl}) -> {tuple(out.shape)}: rel-L2 {e:.3g}, PSNR {p:.1f} dB")
+    assert tuple(out.shape) == (1, 1, 48, 4 * hl, 4 * hl) and e < NET_TOL and float(out.abs().max()) <= 1.0
+    del ref
+    vae.invalidate_engine_cache()
+    _free()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# (d) generate() at BASELINE config 1: one 192x192 patch, 8 -> 48 slices, DDIM-10, full model, injected noise
+# --------------------------------------------------------------------------------------------------------------------
+def _noise_fn(i, shape):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(1000 + i)).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def full_model(pkg):
+    torch.manual_seed(0)
+    model = pkg.VideoToVideoDiffusion(FULL_CFG).eval().to(DEV)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    yield model, sd
+    model.invalidate_engine_cache()
+    _free()
+
+
+def test_generate_config1(full_model):
+    model, sd = full_model
+    v_in = (torch.rand((1, 1, 8, 192, 192), generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    out = model.generate(v_in, 'ddim', num_inference_steps=10, target_depth=48, noise_fn=_noise_fn)
+    assert tuple(out.shape) == (1, 1, 48, 192, 192) and torch.isfinite(out).all()
+    with torch.no_grad():
+        ref = R.generate(sd, UNET_CFG, v_in, "ddim", 10, 48, noise_fn=_noise_fn)
+        with torch.autocast("cuda", dtype=torch.bfloat16):   # the reference's own AMP path on this device
+            ref_bf = R.generate(sd, UNET_CFG, v_in, "ddim", 10, 48, noise_fn=_noise_fn).float()
+    p_hip, p_bf = R.psnr(out, ref, 2.0), R.psnr(ref_bf, ref, 2.0)
+    print(f"generate() config 1: PSNR vs fp32 oracle: hip {p_hip:.2f} dB, oracle under bf16 autocast {p_bf:.2f} dB")
+    assert p_hip >= p_bf - 0.1
+    model.invalidate_engine_cache()
+    _free()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# (e) one config-3 training micro-step: B = 4 patches of 192x192, 8 -> 48 slices, loss + gradients vs the oracle's autograd
+# --------------------------------------------------------------------------------------------------------------------
+def test_training_microstep_config3(full_model):
+    model, sd = full_model
+    B = 4
+    g = torch.Generator().manual_seed(7)
+    v_in = (torch.rand((B, 1, 8, 192, 192), generator=g) * 2 - 1).to(DEV)
+    v_gt = (torch.rand((B, 1, 48, 192, 192), generator=g) * 2 - 1).to(DEV)
+    t = torch.tensor([37, 412, 688, 951], device=DEV)
+    noise = _randn((B, 8, 48, 48, 48), 8).to(DEV)
+    for p in model.parameters():
+        p.grad = None
+    loss, _ = model(v_in, v_gt, t=t, noise=noise)
+    loss.backward()
+    torch.cuda.synchronize()
+    names = ["unet.conv_in.weight", "unet.conv_out.2.weight", "unet.mid_block1.conv1.conv.weight",
+             "unet.down_blocks.0.0.0.conv2.0.weight", "unet.up_blocks.3.0.0.conv1.conv.weight",
+             "unet.up_blocks.3.0.0.residual_conv.weight", "unet.down_samples.0.conv.weight",
+             "unet.up_samples.2.conv.weight", "unet.down_blocks.1.0.0.conv1.norm.weight",
+             "unet.time_embed.time_mlp.1.weight", "unet.mid_attn.proj_out.weight", "unet.up_blocks.0.2.0.time_mlp.1.bias"]
+    pm = dict(model.named_parameters())
+    hip = {k: pm[k].grad.detach().float().clone() for k in names}
+    hip_loss = float(loss)
+    for p in model.parameters():
+        p.grad = None
+    model.invalidate_engine_cache()
+    _free()
+
+    def oracle(autocast):
+        sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+        if autocast:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                l = R.model_training_forward(sdg, UNET_CFG, v_in, v_gt, t, noise)
+        else:
+            l = R.model_training_forward(sdg, UNET_CFG, v_in, v_gt, t, noise)
+        l.float().backward()
+        return float(l), {k: sdg[k].grad.float() for k in names}
+
+    ref_loss, ref_g = oracle(False)
+    _free()
+    ac_loss, ac_g = oracle(True)
+    print(f"config-3 micro-step loss: hip {hip_loss:.6f}, fp32 oracle {ref_loss:.6f}, oracle under bf16 autocast {ac_loss:.6f}")
+    assert abs(hip_loss - ref_loss) <= 2e-2 * abs(ref_loss)
+    for k in names:
+        e_h, e_a = rel_l2(hip[k], ref_g[k]), rel_l2(ac_g[k], ref_g[k])
+        print(f"  grad {k}: hip {e_h:.3g}, autocast {e_a:.3g}")
+        assert e_h <= 2 * e_a + 2e-2, k
+    _free()

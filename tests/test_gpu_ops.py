@@ -119,7 +119,7 @@ HALO3_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["16", "16t62", "16m", "32", "32p", "32n", "32m", "32m62"])
+@pytest.mark.parametrize("tile", ["16", "16m", "32", "32m"])
 @pytest.mark.parametrize("name,c1,c2,cout,dims", HALO3_CASES, ids=[c[0] for c in HALO3_CASES])
 def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     """The LDS halo-tile 3x3x3 kernel (conv3_halo.hip) on aligned, ragged, multi-tile and two-source inputs;
@@ -133,15 +133,11 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     ref = F.conv3d(x, wt, b, padding=1)
     groups = 8
     monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
-    # 4x4x16 tile (16x16x32 MFMA), 4x2x32 tile (32x32x16 MFMA), the persistent-block or the half-size-block 4x2x32 kernel
+    # "16": 4x4x16 tile (16x16x32 MFMA); "32": 4x2x32 tile (32x32x16 MFMA); "32m" / "16m": the 512-voxel kernel in its
+    # 4x4x32 / 4x8x16 form.  (The measured-slower round-1 variants live under csrc/experiments/ and are not built in.)
     monkeypatch.setenv("CTSI_CONV_HALO_TILE", "32" if tile == "16m" else tile[:2])
-    monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile == "16m" else "0")     # 4x8x16 form of the 512-voxel kernel
-    monkeypatch.setenv("CTSI_CONV_HALO16_TILE", "62" if tile == "16t62" else "44")   # 6x2x16 (6 waves) vs 4x4x16
-    monkeypatch.setenv("CTSI_CONV_M512", {"32m": "1", "32m62": "62", "16m": "1"}.get(tile, "0"))   # 4x4x32 / 6x2x32 tiles
-    if tile == "32p":
-        monkeypatch.setenv("CTSI_CONV_PERSIST", "1")
-    if tile == "32n":       # half-size blocks: 4 waves x 64 couts x 16-channel chunks, two blocks per CU
-        monkeypatch.setenv("CTSI_CONV_N64", "1")
+    monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile == "16m" else "0")
+    monkeypatch.setenv("CTSI_CONV_M512", "1" if tile in ("32m", "16m") else "0")
     y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=groups)
     assert rel_l2(y, ref) < CONV_TOL, name
     rg = ref.reshape(n, groups, -1).double()
@@ -151,29 +147,6 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     monkeypatch.setenv("CTSI_CONV_NO_HALO3", "1")
     y2, _ = G.run_conv(x1, x2, wt, b)
     assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
-
-
-@pytest.mark.parametrize("blocks", ["1", "3", "5"])
-def test_conv3_halo_persistent_tile_switching(G, monkeypatch, blocks):
-    """Persistent blocks walking several output tiles each (tile t+1's halo / weights prefetched during tile t,
-    register epilogue under the next tile's MFMAs), incl. ragged edges, two n-tiles and a 2-sample batch."""
-    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
-    monkeypatch.setenv("CTSI_CONV_HALO_TILE", "32")
-    monkeypatch.setenv("CTSI_CONV_PERSIST", "1")
-    monkeypatch.setenv("CTSI_CONV_PERSIST_BLOCKS", blocks)
-    for (c1, c2, cout, dims) in [(64, 0, 256, (2, 6, 5, 40)), (32, 32, 128, (1, 9, 4, 70)), (128, 0, 64, (1, 4, 8, 33))]:
-        n, d, h, w = dims
-        x1 = bf16_round(formula_input((n, c1, d, h, w), 1))
-        x2 = bf16_round(formula_input((n, c2, d, h, w), 2)) if c2 else None
-        x = torch.cat([x1, x2], 1) if c2 else x1
-        wt = bf16_round(_w((cout, c1 + c2, 3, 3, 3), 3))
-        b = formula_input((cout,), 4) * 0.1
-        ref = F.conv3d(x, wt, b, padding=1)
-        y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=8)
-        assert rel_l2(y, ref) < CONV_TOL, (blocks, dims)
-        rg = ref.reshape(n, 8, -1).double()
-        assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
-        assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
 
 
 def test_conv_fp32_strided_output_tanh_and_padded_input(G):

@@ -645,11 +645,8 @@ extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void*
     static bool attr_done = false;
     if (!attr_done) {
         using C44 = H3Cfg<4, 4>;
-        using C62 = H3Cfg<6, 2>;
         auto k44 = conv3_halo_kernel<4, 4>;
-        auto k62 = conv3_halo_kernel<6, 2>;
         hipFuncSetAttribute((const void*)k44, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C44::LDS_BYTES);
-        hipFuncSetAttribute((const void*)k62, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C62::LDS_BYTES);
         hipFuncSetAttribute((const void*)conv3_halo32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h32::LDS_BYTES);
         attr_done = true;
@@ -657,11 +654,7 @@ extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void*
     const int grid = hp->mtiles * hp->ntiles_n;
     if (wide == 1)
         hipLaunchKernelGGL(conv3_halo32_kernel, dim3(grid), dim3(512), h32::LDS_BYTES, (hipStream_t)stream, *hp);
-    else if (wide == 2) {
-        using C62 = H3Cfg<6, 2>;
-        auto k62 = conv3_halo_kernel<6, 2>;
-        hipLaunchKernelGGL(k62, dim3(grid), dim3(C62::NTH), C62::LDS_BYTES, (hipStream_t)stream, *hp);
-    } else {
+    else {
         using C44 = H3Cfg<4, 4>;
         auto k44 = conv3_halo_kernel<4, 4>;
         hipLaunchKernelGGL(k44, dim3(grid), dim3(C44::NTH), C44::LDS_BYTES, (hipStream_t)stream, *hp);

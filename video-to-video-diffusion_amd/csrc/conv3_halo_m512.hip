@@ -335,26 +335,51 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile62 /* 0: 4x4x32, 1: 6x2x32, 2: 4x8x16 */,
-                                           void* stream) {
+// ---- weight packing: fp32 (cout, cin, 3,3,3) -> bf16 [chunk16][tap][cout_pad][16], 16-B halves swizzled per row ----
+__global__ void conv3_halo_c16_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int CoutPad,
+                                           int CinW, int nchunks) {
+    const long long total = (long long)nchunks * 27 * CoutPad * 16;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 15);                 // physical element within the 32-B row
+        const long long row = idx >> 4;                // (chunk*27 + tap)*CoutPad + cout
+        const int co = (int)(row % CoutPad);
+        const long long ct = row / CoutPad;
+        const int tap = (int)(ct % 27), cc = (int)(ct / 27);
+        const int q = (e >> 3) ^ (((co & 63) >> 3) & 1);   // logical half stored in this physical slot (row = co within the 64-cout tile)
+        const int ci = cc * 16 + q * 8 + (e & 7);
+        float v = 0.0f;
+        if (co < Cout && ci < CinW) v = w[((long long)co * CinW + ci) * 27 + tap];
+        out[idx] = f32_to_bf16(v);
+    }
+}
+
+extern "C" int ctsi_conv3_halo_c16_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
+                                        void* stream) {
+    CTSI_CHECK_ARG(w && packed && cin % 16 == 0 && cout_pad % 64 == 0, "ctsi_conv3_halo_c16_pack: bad arguments");
+    const int nchunks = cin / 16;
+    const long long total = (long long)nchunks * 27 * cout_pad * 16;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(conv3_halo_c16_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed,
+                       cout, cout_pad, cin_w, nchunks);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16 */, void* stream) {
     using C44 = HmCfg<4, 4>;
-    using C62 = HmCfg<6, 2>;
     using C48 = HmCfg<4, 8, 16>;
     auto k44 = conv3_halo32m_kernel<4, 4>;
-    auto k62 = conv3_halo32m_kernel<6, 2>;
     auto k48 = conv3_halo32m_kernel<4, 8, 16>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute((const void*)k44, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C44::LDS_BYTES);
-        hipFuncSetAttribute((const void*)k62, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C62::LDS_BYTES);
         hipFuncSetAttribute((const void*)k48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C48::LDS_BYTES);
         attr_done = true;
     }
     const int grid = hp->mtiles * hp->ntiles_n;
-    if (tile62 == 2)
+    if (tile == 2)
         hipLaunchKernelGGL(k48, dim3(grid), dim3(C48::NTH), C48::LDS_BYTES, (hipStream_t)stream, *hp);
-    else if (tile62)
-        hipLaunchKernelGGL(k62, dim3(grid), dim3(C62::NTH), C62::LDS_BYTES, (hipStream_t)stream, *hp);
     else
         hipLaunchKernelGGL(k44, dim3(grid), dim3(C44::NTH), C44::LDS_BYTES, (hipStream_t)stream, *hp);
     CTSI_LAUNCH_CHECK();

@@ -577,10 +577,10 @@ struct ctsi_conv_plan {
     int8_t pH[4], pW[4];
     int tap_margin[4], ad_min[4];
     int fast, dshift;
-    int halo16_62;  // halo3 == 1 only: 6x2x16 tile instead of 4x4x16
-    int m512_62;    // halo3 == 5 only: 1 = 6x2x32 (384 voxels) tile, 2 = 4x8x16 tile, instead of 4x4x32
-    int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip);
-                // 3: 4x2x32 tile, persistent blocks (conv3_halo_persist.hip)
+    int m512_w16;   // halo3 == 5 only: 2 = 4x8x16 tile instead of 4x4x32
+    int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip); 5: 512-voxel tile
+                // (conv3_halo_m512.hip).  3 / 4 were the persistent-block and half-size-block experiments, now under
+                // csrc/experiments/ (measured slower, profiles/r01_notes.md) and no longer built into libctsi.so.
     double flops;
 };
 
@@ -788,50 +788,29 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             bool use_w16 = s512w > s16 && s512w > s32 && s512w > s512;
             if (w16 && !strcmp(w16, "1")) use_w16 = true;
             const char* hv = getenv("CTSI_CONV_HALO_TILE");   // "16" | "32" (tuning aids)
-            const char* m5 = getenv("CTSI_CONV_M512");        // "0" | "1" | "62"
+            const char* m5 = getenv("CTSI_CONV_M512");        // "0" | "1"
             if (hv && !strcmp(hv, "16")) pick = 1;
             if (hv && !strcmp(hv, "32") && pick == 1) pick = s32 >= s512 ? 2 : 5;
             if (m5 && !strcmp(m5, "0") && pick == 5) pick = 2;
-            if (m5 && (!strcmp(m5, "1") || !strcmp(m5, "62")) && pick != 1) pick = 5;
+            if (m5 && !strcmp(m5, "1") && pick != 1) pick = 5;
             if (use_w16 && !(hv && !strcmp(hv, "16")) && !(m5 && !strcmp(m5, "0"))) {
                 pick = 5;
-                p->m512_62 = 2;
-                p->BM = 512;
+                p->m512_w16 = 2;
             }
             p->halo3 = pick;
-            if (pick == 5 && p->m512_62 != 2) {
-                p->m512_62 = m5 && !strcmp(m5, "62");     // 384-voxel 6x2x32 tile: measured behind the 4x2x32 kernel, opt-in
-                p->BM = p->m512_62 ? 384 : 512;
-            }
-            // persistent-block variant: measured slower than the one-tile-per-block kernel (its register epilogue
-            // issues 64 two-byte stores per wave, 0.084 ms of a 0.85 ms layer) -> opt-in only, see profiles/r01_notes.md
-            if (p->halo3 == 2 && getenv("CTSI_CONV_PERSIST") && !getenv("CTSI_CONV_NO_PERSIST")) p->halo3 = 3;
-            // half-size blocks (4 waves, 64 couts, 16-channel chunks, two blocks per CU): conv3_halo_n64.hip, opt-in
-            if (p->halo3 == 2 && getenv("CTSI_CONV_N64") && !strcmp(getenv("CTSI_CONV_N64"), "1")) {
-                p->halo3 = 4;
-                p->BN = 64;
-            }
+            if (pick == 5) p->BM = 512;
         }
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
-    if (p->halo3 == 5 && p->m512_62 == 2) {
+    if (p->halo3 == 5 && p->m512_w16 == 2) {
         p->TD = 4; p->TH = 8; p->TW = 16;
     } else if (p->halo3 == 5) {
-        p->TD = p->m512_62 ? 6 : 4; p->TH = p->m512_62 ? 2 : 4; p->TW = 32;
-    } else if (p->halo3 >= 2) {
+        p->TD = 4; p->TH = 4; p->TW = 32;
+    } else if (p->halo3 == 2) {
         p->TD = 4; p->TH = 2; p->TW = 32;
     } else if (p->halo3) {
         p->TD = 4; p->TH = 4; p->TW = 16;
-        // 6 x 2 x 16 tile (6 waves, conv3_halo_kernel<6,2>): turns the 192 blocks of a 48 x 16 x 16 / 512-cout layer into
-        // exactly 256, but measured SLOWER (734 vs 826 TFLOP/s): each block still streams the full 27 x 8 KB weight slab per
-        // chunk for 25 % fewer voxels, and the weight fill, not the idle quarter of the CUs, bounds these layers.  Opt-in.
-        const char* t62 = getenv("CTSI_CONV_HALO16_TILE");   // "62" (tuning aid)
-        if (t62 && !strcmp(t62, "62")) {
-            p->TD = 6; p->TH = 2;
-            p->BM = 192;
-            p->halo16_62 = 1;
-        }
     } else {
         choose_tile(p->BM, p->Dr, p->Hr, p->Wr, &p->TD, &p->TH, &p->TW);
     }
@@ -881,13 +860,8 @@ extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
     if (p->halo3) return (size_t)(p->Cin / 32) * 27 * p->CoutPad * 64;
     return (size_t)p->nclass * p->CoutPad * p->Ktot * 2;
 }
-// the persistent halo kernel writes one column-sum row per M-wave (4 per tile)
-extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) {
-    return p ? p->nclass * p->mtiles * (p->halo3 == 3 ? 4 : 1) : 0;
-}
-extern "C" int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* p) {
-    return p ? p->tps * (p->halo3 == 3 ? 4 : 1) : 0;
-}
+extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) { return p ? p->nclass * p->mtiles : 0; }
+extern "C" int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* p) { return p ? p->tps : 0; }
 extern "C" int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* p) { return p ? p->CoutPad : 0; }
 extern "C" double ctsi_conv_plan_flops(const ctsi_conv_plan* p) { return p ? p->flops : 0.0; }
 extern "C" int ctsi_conv_plan_config(const ctsi_conv_plan* p, int* bm, int* bn, int* mode) {
@@ -909,7 +883,7 @@ extern "C" int ctsi_conv_plan_set_weight_cin(ctsi_conv_plan* p, int cin_w) {
 extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float* w, void* packed,
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
-    if (p->halo3 >= 4) return ctsi_conv3_halo_n64_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
+    if (p->halo3 == 5) return ctsi_conv3_halo_c16_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
     if (p->halo3) return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
     PackParams q;
     memset(&q, 0, sizeof(q));
@@ -999,7 +973,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         h.dshift = p->dshift;
         h.tilesD = p->tilesD; h.tilesH = p->tilesH; h.tilesW = p->tilesW; h.tps = p->tps; h.mtiles = p->mtiles;
         h.ntiles_n = p->ntiles_n;
-        h.nchunks = p->Cin / (p->halo3 >= 4 ? 16 : 32);
+        h.nchunks = p->Cin / (p->halo3 == 5 ? 16 : 32);
         h.Cout = p->d.cout; h.CoutPad = p->CoutPad;
         h.cout_stride = o->cout_stride; h.c_off = o->c_off;
         {   // n-major block order (one n-tile's 3.5 MB weight slab at a time per XCD instead of all of them: the 48x32x32 /
@@ -1014,21 +988,8 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
         }
-        if (p->halo3 == 4) return ctsi_conv3_halo_n64_launch(&h, stream);
-        if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, p->m512_62, stream);
-        if (p->halo3 == 3) {
-            static int ncu = 0;
-            if (!ncu) {
-                hipDeviceProp_t prop;
-                int dev = 0;
-                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                    ncu = prop.multiProcessorCount;
-                if (ncu <= 0) ncu = 256;
-            }
-            const char* nb_env = getenv("CTSI_CONV_PERSIST_BLOCKS");   // test aid: force tile switching
-            return ctsi_conv3_halo_persist_launch(&h, nb_env ? atoi(nb_env) : ncu, stream);
-        }
-        return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? 1 : (p->halo16_62 ? 2 : 0), stream);
+        if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, p->m512_w16, stream);
+        return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? 1 : 0, stream);
     }
     CTSI_CHECK_ARG(!p->halo3, "ctsi_conv_fwd: the 3x3x3 halo-tile plan supports bf16 NDHWC output without activation");
     ConvKParams k;

@@ -93,9 +93,7 @@ struct Conv3HaloParams {
 extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
                                     void* stream);
 extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void* stream);
-extern "C" int ctsi_conv3_halo_persist_launch(const Conv3HaloParams* hp, int num_blocks, void* stream);
-extern "C" int ctsi_conv3_halo_n64_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
+extern "C" int ctsi_conv3_halo_c16_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
                                         void* stream);
-extern "C" int ctsi_conv3_halo_n64_launch(const Conv3HaloParams* hp, void* stream);
-extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile62, void* stream);
+extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile, void* stream);
 

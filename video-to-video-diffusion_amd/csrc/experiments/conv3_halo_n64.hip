@@ -14,7 +14,7 @@
 // Weight image: [chunk16][27 taps][cout_pad][16], pre-swizzled the same way; a step = the 3 kw taps of one (kd, kh)
 // = 6 KB; the DMA of step s+4 is issued as soon as step s's slot is drained and waits are counted (the DMAs of the
 // two most recent steps may stay in flight).
-#include "conv3_halo_common.h"
+#include "../conv3_halo_common.h"
 #include <stdlib.h>
 
 namespace hn {
@@ -314,36 +314,7 @@ conv3_halo32n_kernel(const Conv3HaloParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-// ---- weight packing: fp32 (cout, cin, 3,3,3) -> bf16 [chunk16][tap][cout_pad][16], 16-B halves swizzled per row ----
-__global__ void conv3_halo_n64_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int CoutPad,
-                                           int CinW, int nchunks) {
-    const long long total = (long long)nchunks * 27 * CoutPad * 16;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx & 15);                 // physical element within the 32-B row
-        const long long row = idx >> 4;                // (chunk*27 + tap)*CoutPad + cout
-        const int co = (int)(row % CoutPad);
-        const long long ct = row / CoutPad;
-        const int tap = (int)(ct % 27), cc = (int)(ct / 27);
-        const int q = (e >> 3) ^ (((co & 63) >> 3) & 1);   // logical half stored in this physical slot (row = co within the 64-cout tile)
-        const int ci = cc * 16 + q * 8 + (e & 7);
-        float v = 0.0f;
-        if (co < Cout && ci < CinW) v = w[((long long)co * CinW + ci) * 27 + tap];
-        out[idx] = f32_to_bf16(v);
-    }
-}
-
-extern "C" int ctsi_conv3_halo_n64_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
-                                        void* stream) {
-    CTSI_CHECK_ARG(w && packed && cin % 16 == 0 && cout_pad % 64 == 0, "ctsi_conv3_halo_n64_pack: bad arguments");
-    const int nchunks = cin / 16;
-    const long long total = (long long)nchunks * 27 * cout_pad * 16;
-    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(conv3_halo_n64_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed,
-                       cout, cout_pad, cin_w, nchunks);
-    CTSI_LAUNCH_CHECK();
-    return CTSI_OK;
-}
+// (the [chunk16][tap][cout_pad][16] weight packing this kernel reads lives in ../conv3_halo_m512.hip: ctsi_conv3_halo_c16_pack)
 
 extern "C" int ctsi_conv3_halo_n64_launch(const Conv3HaloParams* hp, void* stream) {
     static bool attr_done = false;

@@ -15,7 +15,7 @@
 //     wait after them is a counted vmcnt(63), every older DMA is complete by then);
 //   * per-wave partial column sums go to 4 slab rows per tile (the GroupNorm finalize kernel just sees 4x
 //     more tiles), so the epilogue needs no cross-wave reduction either.
-#include "conv3_halo_common.h"
+#include "../conv3_halo_common.h"
 #include <string.h>
 
 namespace h32p {

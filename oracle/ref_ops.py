@@ -44,6 +44,33 @@ def conv3d(sd: SD, p: str, x, stride=1, padding=0):
     return F.conv3d(x, sd[p + ".weight"], sd[p + ".bias"], stride=stride, padding=padding)
 
 
+CONVT_AS_CONV = False   # see conv_transpose_122
+
+
+def conv_transpose_122(x, weight, bias):
+    """nn.ConvTranspose3d(k=(3,4,4), stride=(1,2,2), padding=1) (ref models/unet3d.py:218-221, models/vae.py:86-90).
+    Default: PyTorch's own F.conv_transpose3d.  With CONVT_AS_CONV the same sum is evaluated as a stride-1 Conv3d over
+    the zero-inserted input with the flipped, (cin, cout)-transposed kernel and padding k-1-p = (1,2,2) -- the textbook
+    identity, bit-for-bit the same products in a different summation order (tests/test_oracle_golden.py holds the two
+    to 1e-6).  The GPU parity tests use it at the 512^2 sizes because MIOpen's fp32 backward-data path (which
+    F.conv_transpose3d maps to) spends minutes searching for / running a solver there, while its forward path does not."""
+    if not CONVT_AS_CONV:
+        return F.conv_transpose3d(x, weight, bias, stride=(1, 2, 2), padding=(1, 1, 1))
+    n, c, d, h, w = x.shape
+    up = x.new_zeros((n, c, d, 2 * h - 1, 2 * w - 1))
+    up[:, :, :, ::2, ::2] = x
+    wf = weight.flip(2, 3, 4).transpose(0, 1).contiguous()      # (cout, cin, 3, 4, 4)
+    # MIOpen has no implicit-GEMM instance for (3,4,4) kernels and falls back to im2col + GEMM: its workspace is
+    # cin * 48 taps * output voxels * 4 B (576 GiB for the VAE's last upsample at 512^2) -> evaluate depth slabs
+    per_slice = c * 48 * (2 * h) * (2 * w) * 4 * n
+    cd = max(1, min(d, int((32 << 30) // max(per_slice, 1))))
+    if cd >= d:
+        return F.conv3d(up, wf, bias, padding=(1, 2, 2))
+    up = F.pad(up, (0, 0, 0, 0, 1, 1))
+    return torch.cat([F.conv3d(up[:, :, d0:d0 + min(cd, d - d0) + 2], wf, bias, padding=(0, 2, 2))
+                      for d0 in range(0, d, cd)], dim=2)
+
+
 def gn(sd: SD, p: str, x, groups: int):
     return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps=1e-5)
 
@@ -132,8 +159,7 @@ def unet_forward(sd: SD, cfg: dict, x, t, c, prefix: str = "", taps: Optional[di
             if src in att:
                 h = temporal_attention(sd, f"{P}up_blocks.{lvl}.{b}.1", h, heads)
         if lvl < levels - 1:
-            h = F.conv_transpose3d(h, sd[f"{P}up_samples.{lvl}.conv.weight"], sd[f"{P}up_samples.{lvl}.conv.bias"],
-                                   stride=(1, 2, 2), padding=(1, 1, 1))
+            h = conv_transpose_122(h, sd[f"{P}up_samples.{lvl}.conv.weight"], sd[f"{P}up_samples.{lvl}.conv.bias"])
     cfin = h.shape[1]
     h = F.silu(gn(sd, P + "conv_out.0", h, group_count(cfin)))
     return conv3d(sd, P + "conv_out.2", h, padding=1)
@@ -143,7 +169,7 @@ def unet_forward(sd: SD, cfg: dict, x, t, c, prefix: str = "", taps: Optional[di
 def vae_conv_block(sd: SD, p: str, x, stride=1, transposed=False):
     """ref models/vae.py:31-35, 72-76, 93-97 (GroupNorm always 8 groups)"""
     if transposed:
-        h = F.conv_transpose3d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], stride=(1, 2, 2), padding=(1, 1, 1))
+        h = conv_transpose_122(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"])
     else:
         h = F.conv3d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], stride=stride, padding=(1, 1, 1))
     return F.silu(gn(sd, p + ".norm", h, 8))

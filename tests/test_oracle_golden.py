@@ -144,6 +144,24 @@ def test_vae_tiny(golden, pkg):
     assert rel_l2(R.vae_decode(sd, z, 0.5), golden["vae.tiny.recon"]) < TOL
 
 
+def test_conv_transpose_as_conv_path_matches_reference_goldens(golden, pkg, monkeypatch):
+    """oracle.ref_ops.CONVT_AS_CONV (zero insertion + flipped-kernel Conv3d, used by the 512^2 GPU parity tests) against
+    the same goldens from the reference as the default F.conv_transpose3d path."""
+    monkeypatch.setattr(R, "CONVT_AS_CONV", True)
+    U = _U()
+    un3 = U.UNet3D(**MID_UNET)
+    sd3 = formula_sd(un3, 9)
+    out3 = R.unet_forward(sd3, unet_cfg(MID_UNET), formula_input((1, 4, 6, 12, 8), 12), torch.tensor([999]),
+                          formula_input((1, 4, 6, 12, 8), 13))
+    assert rel_l2(out3, golden["unet.mid.out"]) < TOL
+    vae = pkg.VideoVAE(in_channels=1, latent_dim=8, base_channels=16, scaling_factor=0.5)
+    sd = formula_sd(vae, 10)
+    assert rel_l2(R.vae_decode(sd, torch.tensor(golden["vae.tiny.latent"]), 0.5), golden["vae.tiny.recon"]) < TOL
+    x, w, b = formula_input((2, 16, 3, 5, 7), 1), formula_input((16, 8, 3, 4, 4), 2) * 0.1, formula_input((8,), 3)
+    ref = torch.nn.functional.conv_transpose3d(x, w, b, stride=(1, 2, 2), padding=(1, 1, 1))
+    assert rel_l2(R.conv_transpose_122(x, w, b), ref) < 1e-6
+
+
 def test_sampler_trajectories(golden, pkg):
     _, sd, cfg = tiny_model_sd(pkg)
     shape = (1, 8, 4, 8, 8)

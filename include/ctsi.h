@@ -127,7 +127,8 @@ int ctsi_conv_fwd(const ctsi_conv_plan* plan, const void* x1, const void* x2, co
 int ctsi_gn_colsum(const void* x_bf16, float* colsum, int n, int c, int d, int h, int w,
                    int* tiles_per_sample, void* stream);
 int ctsi_gn_colsum_tiles(int d, int h, int w);
-/* sums[n][g][2] (double) += over tiles/columns.  `sums` must be zeroed by the caller.
+/* sums[n][g][2] (double) = sum over tiles/columns: WRITTEN, not accumulated (no zeroing needed), by one block per
+ * (sample, group) with a fixed-order reduce -- bit-identical from run to run (no atomics).
  * nclass > 1: tiles of class k of sample i start at (k*n + i)*tiles_per_sample.          */
 int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c, int c_pad, int groups,
                      int tiles_per_sample, int nclass, void* stream);

@@ -116,10 +116,12 @@ HALO3_CASES = [
     ("concat_256+128", 256, 128, 128, (1, 4, 5, 16)),
     ("cin32_cout_72_pad", 32, 0, 72, (1, 2, 3, 9)),
     ("cin512_deep_k", 512, 0, 128, (1, 2, 4, 16)),
+    ("cin16_stem_two_sources", 16, 16, 128, (1, 4, 5, 33)),     # 16-channel sources: the 512-voxel kernel only
+    ("cin16_unet_stem", 16, 0, 128, (2, 3, 8, 32)),
 ]
 
 
-@pytest.mark.parametrize("tile", ["16", "16m", "32", "32m"])
+@pytest.mark.parametrize("tile", ["16", "16h", "16m", "32", "32m"])
 @pytest.mark.parametrize("name,c1,c2,cout,dims", HALO3_CASES, ids=[c[0] for c in HALO3_CASES])
 def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     """The LDS halo-tile 3x3x3 kernel (conv3_halo.hip) on aligned, ragged, multi-tile and two-source inputs;
@@ -133,10 +135,11 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     ref = F.conv3d(x, wt, b, padding=1)
     groups = 8
     monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
-    # "16": 4x4x16 tile (16x16x32 MFMA); "32": 4x2x32 tile (32x32x16 MFMA); "32m" / "16m": the 512-voxel kernel in its
-    # 4x4x32 / 4x8x16 form.  (The measured-slower round-1 variants live under csrc/experiments/ and are not built in.)
+    # "16": 4x4x16 tile (16x16x32 MFMA); "16h": 4x4x16 tile on the 32x32x16-MFMA kernel (two W-lines per A tile); "32":
+    # 4x2x32 tile (32x32x16 MFMA); "32m" / "16m": the 512-voxel kernel in its 4x4x32 / 4x8x16 form.  (The measured-slower round-1 variants live under csrc/experiments/ and are not built in.)
     monkeypatch.setenv("CTSI_CONV_HALO_TILE", "32" if tile == "16m" else tile[:2])
     monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile == "16m" else "0")
+    monkeypatch.setenv("CTSI_CONV_H32W16", "1" if tile == "16h" else "0")
     monkeypatch.setenv("CTSI_CONV_M512", "1" if tile in ("32m", "16m") else "0")
     y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=groups)
     assert rel_l2(y, ref) < CONV_TOL, name
@@ -165,6 +168,42 @@ def test_conv_fp32_strided_output_tanh_and_padded_input(G):
     w1 = bf16_round(_w((32, 1, 3, 3, 3), 9))
     y, _ = G.run_conv(x1, None, w1, None, c1_pad=8, cin_w=1)
     assert rel_l2(y, F.conv3d(x1, w1, None, padding=1)) < CONV_TOL
+
+
+HEAD_CASES = [
+    # name, cin, cout, (n,d,h,w), f32, act
+    ("unet_head_128_8_f32", 128, 8, (1, 4, 8, 32), True, 0),
+    ("vae_head_128_1_tanh", 128, 1, (1, 3, 6, 20), True, 1),
+    ("ragged_batch2_64_4", 64, 4, (2, 5, 7, 21), True, 0),
+    ("cout16_bf16_stats", 32, 16, (1, 2, 9, 17), False, 0),
+    ("cout8_bf16_stats_deep", 256, 8, (2, 3, 4, 16), False, 0),
+]
+
+
+@pytest.mark.parametrize("name,cin,cout,dims,f32,act", HEAD_CASES, ids=[c[0] for c in HEAD_CASES])
+def test_conv3_head_kernel(G, monkeypatch, name, cin, cout, dims, f32, act):
+    """conv3_head.hip: 3x3x3 convs with <= 16 output channels on a 2x4x16 halo tile (fp32 strided output with optional
+    tanh, or bf16 NDHWC + GroupNorm column sums); the gather-GEMM kernel must agree on the same problem."""
+    n, d, h, w = dims
+    x = bf16_round(formula_input((n, cin, d, h, w), 31))
+    wt = bf16_round(_w((cout, cin, 3, 3, 3), 32))
+    b = formula_input((cout,), 33) * 0.1
+    ref = F.conv3d(x, wt, b, padding=1)
+    if act:
+        ref = torch.tanh(ref)
+    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
+    groups = 1 if cout < 8 else cout // 4
+    y, sums = G.run_conv(x, None, wt, b, f32=f32, act=act, want_stats=not f32, groups=groups)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert rel_l2(y, ref) < (2e-4 if f32 else CONV_TOL), name
+    if not f32:
+        rg = ref.reshape(n, groups, -1).double()
+        assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+        assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
+    monkeypatch.delenv("CTSI_CONV_FORCE_HALO3")
+    monkeypatch.setenv("CTSI_CONV_NO_HEAD3", "1")
+    y2, _ = G.run_conv(x, None, wt, b, f32=f32, act=act)
+    assert float((y - y2).abs().max()) <= (1e-4 if f32 else 2.0 ** -7) * float(ref.abs().max())
 
 
 def test_conv_linearity_and_zero_padding_property(G):

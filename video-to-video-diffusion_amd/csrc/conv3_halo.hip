@@ -333,10 +333,38 @@ conv3_halo_kernel(const Conv3HaloParams p) {
 // port for 8 of its 16 cycles, the 32x32x16 form for 8 of 32), used whenever W >= 32-ish.
 // =====================================================================================================
 
+// Tile shapes: <2,32> = 4 x 2 x 32 voxels (an A tile of 32 rows = one W-line) and <4,16> = 4 x 4 x 16 voxels for 16-wide
+// levels (an A tile = two W-lines of 16: lanes 16-31 read the next H line), so that the 48 x 16 x 16 level runs on
+// 32x32x16 MFMAs with half the LDS reads per flop of conv3_halo_kernel's 16x16x32 form.
+template <int TH_, int TW_>
+struct H32Cfg {
+    static constexpr int TD = 4, TH = TH_, TW = TW_;
+    static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+    static constexpr int HV = HD * HH * HW;               // <2,32>: 816 halo voxels, <4,16>: 648
+    static constexpr int HALO_INSTR = (HV + 15) / 16;     // 51 / 41
+    static constexpr int HALO_BYTES = HALO_INSTR * 1024;
+    static constexpr int BM = TD * TH * TW;               // 256
+    static constexpr int BN = 128;
+    static constexpr int LPT = 32 / TW;                   // W-lines per 32-row A tile
+    static constexpr int WSLOT_BYTES = 3 * BN * 64;
+    static constexpr int NTH = 512;
+    static constexpr int OFF_W = 2 * HALO_BYTES;
+    static constexpr int OFF_ROW = OFF_W + 2 * WSLOT_BYTES;
+    static constexpr int OFF_CS = OFF_ROW + BM * 8;
+    static constexpr int LDS_BYTES = OFF_CS + 4 * BN * 8;  // 159744 <= 163840
+    static constexpr int NPIECE = (HALO_INSTR + 7) / 8;    // halo DMA instructions per wave and chunk (issued at g < NPIECE)
+    static_assert(BM == 256 && TH * TW == 64 && NPIECE <= 9 && LDS_BYTES <= 160 * 1024, "unsupported tile");
+};
+
+template <int TH_, int TW_>
 __global__ void __launch_bounds__(512)
 conv3_halo32_kernel(const Conv3HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using namespace h32;
+    using Cfg = H32Cfg<TH_, TW_>;
+    constexpr int TD = Cfg::TD, TH = Cfg::TH, TW = Cfg::TW, HH = Cfg::HH, HW = Cfg::HW, HV = Cfg::HV, LPT = Cfg::LPT;
+    constexpr int HALO_INSTR = Cfg::HALO_INSTR, HALO_BYTES = Cfg::HALO_BYTES, BM = Cfg::BM, BN = Cfg::BN, NTH = Cfg::NTH;
+    constexpr int WSLOT_BYTES = Cfg::WSLOT_BYTES, OFF_W = Cfg::OFF_W, OFF_ROW = Cfg::OFF_ROW, OFF_CS = Cfg::OFF_CS;
+    constexpr int NPIECE = Cfg::NPIECE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long* s_rowoff = reinterpret_cast<long long*>(smem + OFF_ROW);
     float* s_cs = reinterpret_cast<float*>(smem + OFF_CS);
@@ -358,8 +386,8 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
     const int tW = r0 - tH * p.tilesW;
     const int d0 = tD * TD, h0 = tH * TH, w0 = tW * TW;
 
-    if (tid < BM) {   // row = line*32 + m, line = ld*TH + lh
-        const int mm = tid & 31, line = tid >> 5;
+    if (tid < BM) {   // row = line*TW + m, line = ld*TH + lh
+        const int mm = tid % TW, line = tid / TW;
         const int d = d0 + line / TH, h = h0 + line % TH, w = w0 + mm;
         long long off = -1;
         if (d < p.Do && h < p.Ho && w < p.Wo)
@@ -420,7 +448,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
 
     // fragment addressing: lane -> row r = lane & 31 of the 32-row operand tile, k-group hk = lane >> 5
     const int hk = lane >> 5, r = lane & 31;
-    const int va = (wm * HH) * HW + r;                       // halo voxel of (ld = wm, lh = 0) before taps
+    const int va = (wm * HH + r / TW) * HW + r % TW;         // halo voxel of this lane's row in A tile 0 (ld = wm), before taps
     const int rowb = wn * 64 + r;
     const int b_off = rowb * 64 + ((hk ^ ((rowb >> 2) & 3)) << 4);   // k-step 0; k-step 1 = ^32; n-tile 1 = +2048
 
@@ -444,7 +472,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
 #define H32_LOAD(FA, FB, HBUF, WBUF, VS, KW)                                                                   \
     {                                                                                                          \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
-            const int v_ = (VS) + i_ * HW + (KW);                                                              \
+            const int v_ = (VS) + i_ * (LPT * HW) + (KW);                                                      \
             const int o_ = v_ * 64 + ((hk ^ ((v_ >> 2) & 3)) << 4);                                            \
             FA[i_][0] = *reinterpret_cast<const bf16x8*>((HBUF) + o_);                                         \
             FA[i_][1] = *reinterpret_cast<const bf16x8*>((HBUF) + (o_ ^ 32));                                  \
@@ -647,13 +675,18 @@ extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void*
         using C44 = H3Cfg<4, 4>;
         auto k44 = conv3_halo_kernel<4, 4>;
         hipFuncSetAttribute((const void*)k44, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C44::LDS_BYTES);
-        hipFuncSetAttribute((const void*)conv3_halo32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)h32::LDS_BYTES);
+        hipFuncSetAttribute((const void*)conv3_halo32_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)H32Cfg<2, 32>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)conv3_halo32_kernel<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)H32Cfg<4, 16>::LDS_BYTES);
         attr_done = true;
     }
     const int grid = hp->mtiles * hp->ntiles_n;
+    constexpr int lds_232 = H32Cfg<2, 32>::LDS_BYTES, lds_416 = H32Cfg<4, 16>::LDS_BYTES;
     if (wide == 1)
-        hipLaunchKernelGGL(conv3_halo32_kernel, dim3(grid), dim3(512), h32::LDS_BYTES, (hipStream_t)stream, *hp);
+        hipLaunchKernelGGL((conv3_halo32_kernel<2, 32>), dim3(grid), dim3(512), lds_232, (hipStream_t)stream, *hp);
+    else if (wide == 3)
+        hipLaunchKernelGGL((conv3_halo32_kernel<4, 16>), dim3(grid), dim3(512), lds_416, (hipStream_t)stream, *hp);
     else {
         using C44 = H3Cfg<4, 4>;
         auto k44 = conv3_halo_kernel<4, 4>;

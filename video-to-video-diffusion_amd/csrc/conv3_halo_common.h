@@ -56,21 +56,3 @@ __device__ __forceinline__ int xcd_remap_h(int orig, int nwg) {
     const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + (orig >> 3);
 }
-
-
-namespace h32 {
-constexpr int TD = 4, TH = 2, TW = 32;
-constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
-constexpr int HV = HD * HH * HW;               // 816 halo voxels
-constexpr int HALO_INSTR = (HV + 15) / 16;     // 51
-constexpr int HALO_BYTES = HALO_INSTR * 1024;  // 52224
-constexpr int BM = TD * TH * TW;               // 256
-constexpr int BN = 128;
-constexpr int WSLOT_BYTES = 3 * BN * 64;
-constexpr int NTH = 512;
-constexpr int OFF_W = 2 * HALO_BYTES;
-constexpr int OFF_ROW = OFF_W + 2 * WSLOT_BYTES;
-constexpr int OFF_CS = OFF_ROW + BM * 8;
-constexpr int LDS_BYTES = OFF_CS + 4 * BN * 8;  // 159744 <= 163840
-constexpr int NPIECE = (HALO_INSTR + 7) / 8;   // 7 halo DMA instructions per wave and chunk
-}  // namespace h32

@@ -224,23 +224,29 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     __builtin_amdgcn_sched_barrier(0);
 
     int cc = 0, g = 0;
+#define HM_SYNC_ISSUE()                                                                                        \
+    {                                                                                                          \
+        /* slot s is drained by this wave once the loads above have returned.  Needed next: weights of step    \
+           s+1 (issued 3 steps ago); the next chunk's halo pieces are issued at g < NPIECE <= 6, so they are   \
+           older than the two most recent steps' DMAs by the time they are read (g = 8). */                    \
+        hm_wait_vm(n_prev1 + n_prev2);                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        int issued = 0;                                                                                        \
+        if (s + NWS < S && !(p.dbg & 2)) issued += issue_weights(s + NWS);                                     \
+        if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1))                                                    \
+            issued += issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);                                      \
+        n_prev2 = n_prev1;                                                                                     \
+        n_prev1 = issued;                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
     for (int s = 0; s < S; ++s) {
         const char* hbuf = smem + (cc & 1) * HALO_BYTES;
         const char* wbuf = smem + OFF_W + (s % NWS) * WSLOT_BYTES;
         const int kd = g / 3, kh = g - kd * 3;
         const int vs = (kd * HH + kh) * HW;
         HN_PHASE(fa0, fb0, fa2, fb2, hbuf, wbuf, vs, 2);
-        // slot s is drained by this wave once the loads above have returned.  Needed next: weights of step s+1 (issued 3
-        // steps ago); the next chunk's halo pieces are issued at g < NPIECE <= 6, so they are older than the two most recent
-        // steps' DMAs by the time they are read (g = 8).
-        hm_wait_vm(n_prev1 + n_prev2);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        int issued = 0;
-        if (s + NWS < S && !(p.dbg & 2)) issued += issue_weights(s + NWS);
-        if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1)) issued += issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
-        n_prev2 = n_prev1;
-        n_prev1 = issued;
+        HM_SYNC_ISSUE();
         int g2 = g + 1, cc2 = cc;
         if (g2 == 9) {
             g2 = 0;
@@ -257,6 +263,7 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
         g = g2;
         cc = cc2;
     }
+#undef HM_SYNC_ISSUE
 #undef HN_PHASE
 #undef HN_LOAD
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -577,6 +577,7 @@ struct ctsi_conv_plan {
     int8_t pH[4], pW[4];
     int tap_margin[4], ad_min[4];
     int fast, dshift;
+    int h32_w16;    // halo3 == 2 only: 1 = 4x4x16 tile (two W-lines of 16 per A tile) instead of 4x2x32
     int m512_w16;   // halo3 == 5 only: 2 = 4x8x16 tile instead of 4x4x32
     int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip); 5: 512-voxel tile
                 // (conv3_halo_m512.hip).  3 / 4 were the persistent-block and half-size-block experiments, now under
@@ -764,7 +765,11 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
         const long long padded = (long long)ceil_div(p->Dr, 4) * ceil_div(p->Hr, 4) * ceil_div(p->Wr, 16) * 256;
         const int cmax = d.c1 > d.c2 ? d.c1 : d.c2;
         const double extent = 8.0 * d.hi * d.wi * cmax * 2.0;
-        p->halo3 = k3 && !p->small && d.c1 % 32 == 0 && d.c2 % 32 == 0 && d.cout >= 64 && d.cout % 8 == 0 &&
+        // whole 32-channel chunks per source for the 4x4x16 / 4x2x32 kernels; the 512-voxel kernel walks 16-channel chunks,
+        // so sources of 16 channels (the U-Net stem: [z | cond] = 2 x latent_dim = 16) can use it too
+        const bool c32 = !p->small && d.c1 % 32 == 0 && d.c2 % 32 == 0;
+        const bool c16 = d.c1 % 16 == 0 && d.c2 % 16 == 0 && !getenv("CTSI_CONV_NO_C16");
+        p->halo3 = k3 && (c32 || c16) && d.cout >= 64 && d.cout % 8 == 0 &&
                    p->CinW == p->Cin && (rows * 10 >= padded * 7 || getenv("CTSI_CONV_FORCE_HALO3")) && extent < 2.0e9 &&
                    !getenv("CTSI_CONV_NO_HALO3");
         if (p->halo3) {
@@ -793,12 +798,31 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             if (hv && !strcmp(hv, "32") && pick == 1) pick = s32 >= s512 ? 2 : 5;
             if (m5 && !strcmp(m5, "0") && pick == 5) pick = 2;
             if (m5 && !strcmp(m5, "1") && pick != 1) pick = 5;
-            if (use_w16 && !(hv && !strcmp(hv, "16")) && !(m5 && !strcmp(m5, "0"))) {
+            if (!c32 && pick != 5) {   // 16-channel sources: only the 512-voxel kernel applies
+                pick = 5;
+                use_w16 = s512w > s512;
+            }
+            if (use_w16 && (!c32 || (!(hv && !strcmp(hv, "16")) && !(m5 && !strcmp(m5, "0"))))) {
                 pick = 5;
                 p->m512_w16 = 2;
             }
+            {   // 16-wide levels on the 32x32x16-MFMA kernel (4x4x16 tile) instead of conv3_halo_kernel's 16x16x32 form
+                const char* hw = getenv("CTSI_CONV_H32W16");   // "0" | "1" (tuning aid)
+                if (pick == 1 && !(hw && !strcmp(hw, "0"))) {
+                    pick = 2;
+                    p->h32_w16 = 1;
+                }
+            }
             p->halo3 = pick;
             if (pick == 5) p->BM = 512;
+        }
+        // few output channels (network heads: 128 -> 8, 128 -> 1): halo tile 2x4x16 x 16 couts, see conv3_head.hip
+        const long long padded_h = (long long)ceil_div(p->Dr, 2) * ceil_div(p->Hr, 4) * ceil_div(p->Wr, 16) * 128;
+        if (!p->halo3 && k3 && !p->small && d.c2 == 0 && d.c1 % 32 == 0 && d.cout <= 16 && (rows * 10 >= padded_h * 7 || getenv("CTSI_CONV_FORCE_HALO3")) &&
+            extent < 2.0e9 && !getenv("CTSI_CONV_NO_HEAD3")) {
+            p->halo3 = 6;
+            p->BM = 128;
+            p->BN = 16;
         }
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
@@ -808,7 +832,9 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     } else if (p->halo3 == 5) {
         p->TD = 4; p->TH = 4; p->TW = 32;
     } else if (p->halo3 == 2) {
-        p->TD = 4; p->TH = 2; p->TW = 32;
+        p->TD = 4; p->TH = p->h32_w16 ? 4 : 2; p->TW = p->h32_w16 ? 16 : 32;
+    } else if (p->halo3 == 6) {
+        p->TD = 2; p->TH = 4; p->TW = 16;
     } else if (p->halo3) {
         p->TD = 4; p->TH = 4; p->TW = 16;
     } else {
@@ -857,7 +883,7 @@ extern "C" int ctsi_conv_plan_out_dims(const ctsi_conv_plan* p, int* d, int* h, 
 }
 extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
     if (!p) return 0;
-    if (p->halo3) return (size_t)(p->Cin / 32) * 27 * p->CoutPad * 64;
+    if (p->halo3) return (size_t)p->Cin * 27 * p->CoutPad * 2;   // [chunk][27][cout_pad][32 | 16 ch] bf16
     return (size_t)p->nclass * p->CoutPad * p->Ktot * 2;
 }
 extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) { return p ? p->nclass * p->mtiles : 0; }
@@ -958,7 +984,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
                        "ctsi_conv_fwd: bf16 output needs cout, cout_stride, c_off multiples of 8 "
                        "(cout=%d stride=%d off=%d)", p->d.cout, o->cout_stride, o->c_off);
     }
-    if (p->halo3 && o->mode == 0 && o->act == 0) {
+    if (p->halo3 && (p->halo3 == 6 || (o->mode == 0 && o->act == 0))) {
         Conv3HaloParams h;
         memset(&h, 0, sizeof(h));
         h.x1 = (const bf16_t*)x1;
@@ -988,8 +1014,10 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
         }
+        if (p->halo3 == 6)
+            return ctsi_conv3_head_launch(&h, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
         if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, p->m512_w16, stream);
-        return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? 1 : 0, stream);
+        return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? (p->h32_w16 ? 3 : 1) : 0, stream);
     }
     CTSI_CHECK_ARG(!p->halo3, "ctsi_conv_fwd: the 3x3x3 halo-tile plan supports bf16 NDHWC output without activation");
     ConvKParams k;

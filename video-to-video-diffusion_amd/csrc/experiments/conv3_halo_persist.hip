@@ -19,6 +19,22 @@
 #include <string.h>
 
 namespace h32p {
+namespace h32 {   // tile constants of the 4 x 2 x 32 kernel this experiment was derived from
+constexpr int TD = 4, TH = 2, TW = 32;
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+constexpr int HV = HD * HH * HW;
+constexpr int HALO_INSTR = (HV + 15) / 16;
+constexpr int HALO_BYTES = HALO_INSTR * 1024;
+constexpr int BM = TD * TH * TW;
+constexpr int BN = 128;
+constexpr int WSLOT_BYTES = 3 * BN * 64;
+constexpr int NTH = 512;
+constexpr int OFF_W = 2 * HALO_BYTES;
+constexpr int OFF_ROW = OFF_W + 2 * WSLOT_BYTES;
+constexpr int OFF_CS = OFF_ROW + BM * 8;
+constexpr int LDS_BYTES = OFF_CS + 4 * BN * 8;
+constexpr int NPIECE = (HALO_INSTR + 7) / 8;
+}  // namespace h32
 using namespace h32;
 // three rotating s_rowoff buffers (tile k uses buffer k % 3): the next tile's offsets are written while slow
 // waves may still read the previous tile's buffer in their epilogue; the column-sum scratch is not needed

@@ -91,32 +91,47 @@ extern "C" int ctsi_gn_colsum(const void* x, float* colsum, int n, int c, int d,
 }
 
 // ---- finalize: column-sum slab -> (sum, sumsq) per (sample, group), fp64 -----------------------
-// grid: (groups, n, slices); block 256.
-__global__ void __launch_bounds__(256)
+// grid: (groups, n); block 1024.  ONE block owns one (sample, group): every thread sums a fixed, strided subset of the
+// tile partials in a fixed order, the block combines them with a fixed-shape tree, and the result is WRITTEN (not
+// accumulated) -- the statistics are bit-identical from run to run by construction (no atomics, no dependence on block
+// scheduling), and the sums buffer needs no zeroing.
+__global__ void __launch_bounds__(1024)
 gn_finalize_kernel(const float* __restrict__ colsum, double* __restrict__ sums, int n_total, int c_pad,
-                   int groups, int cpg, int tps, int nclass, int tiles_per_slice) {
-    const int g = blockIdx.x, nb = blockIdx.y, slice = blockIdx.z;
+                   int groups, int cpg, int tps, int nclass) {
+    const int g = blockIdx.x, nb = blockIdx.y;
     const int tid = threadIdx.x;
     const long long slab = (long long)nclass * n_total * tps * c_pad;
-    const int t0 = slice * tiles_per_slice;
-    int t1 = t0 + tiles_per_slice;
-    if (t1 > tps) t1 = tps;
-    double a1 = 0.0, a2 = 0.0;
-    const int items = (t1 - t0) * cpg;
+    const int items = tps * cpg;
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
     for (int cls = 0; cls < nclass; ++cls) {
         const long long tbase = ((long long)cls * n_total + nb) * tps;
-        for (int it = tid; it < items; it += 256) {
-            const int t = t0 + it / cpg, col = g * cpg + it % cpg;
-            const long long idx = (tbase + t) * c_pad + col;
-            a1 += (double)colsum[idx];
-            a2 += (double)colsum[slab + idx];
+        int it = tid;
+        for (; it + 3 * 1024 < items; it += 4 * 1024) {   // four independent loads in flight per statistic
+            float v1[4], v2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i2 = it + u * 1024;
+                const long long idx = (tbase + i2 / cpg) * c_pad + g * cpg + i2 % cpg;
+                v1[u] = colsum[idx];
+                v2[u] = colsum[slab + idx];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a1[u] += (double)v1[u];
+                a2[u] += (double)v2[u];
+            }
+        }
+        for (int u = 0; it < items; it += 1024, ++u) {
+            const long long idx = (tbase + it / cpg) * c_pad + g * cpg + it % cpg;
+            a1[u] += (double)colsum[idx];
+            a2[u] += (double)colsum[slab + idx];
         }
     }
-    __shared__ double s1[256], s2[256];
-    s1[tid] = a1;
-    s2[tid] = a2;
+    __shared__ double s1[1024], s2[1024];
+    s1[tid] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    s2[tid] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = 512; off > 0; off >>= 1) {
         if (tid < off) {
             s1[tid] += s1[tid + off];
             s2[tid] += s2[tid + off];
@@ -124,8 +139,8 @@ gn_finalize_kernel(const float* __restrict__ colsum, double* __restrict__ sums, 
         __syncthreads();
     }
     if (tid == 0) {
-        atomicAdd(&sums[((long long)nb * groups + g) * 2 + 0], s1[0]);
-        atomicAdd(&sums[((long long)nb * groups + g) * 2 + 1], s2[0]);
+        sums[((long long)nb * groups + g) * 2 + 0] = s1[0];
+        sums[((long long)nb * groups + g) * 2 + 1] = s2[0];
     }
 }
 
@@ -134,11 +149,8 @@ extern "C" int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c,
     CTSI_CHECK_ARG(colsum && sums, "ctsi_gn_finalize: null argument");
     CTSI_CHECK_ARG(groups > 0 && c % groups == 0, "ctsi_gn_finalize: c=%d not divisible by groups=%d", c, groups);
     const int cpg = c / groups;
-    int per_slice = 4096 / cpg;  // ~4096 floats per block and statistic
-    if (per_slice < 1) per_slice = 1;
-    const int slices = ceil_div(tiles_per_sample, per_slice);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n, slices), dim3(256), 0, (hipStream_t)stream, colsum,
-                       sums, n, c_pad, groups, cpg, tiles_per_sample, nclass, per_slice);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n), dim3(1024), 0, (hipStream_t)stream, colsum, sums, n, c_pad,
+                       groups, cpg, tiles_per_sample, nclass);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }
@@ -180,19 +192,20 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const doub
     const long long stride = (long long)gridDim.x * 256;
     const int dq = (int)(stride % cpr);
     int q = (int)(((long long)blockIdx.x * 256 + tid) % cpr);   // 8-channel chunk index inside the voxel row
-    for (long long e = (long long)blockIdx.x * 256 + tid; e < total; e += stride, q = (q + dq >= cpr) ? q + dq - cpr : q + dq) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(xb + e * 8);
+    constexpr int U = 4;   // independent 16-byte loads in flight per thread (HBM latency, not issue, bounds this kernel)
+    long long e = (long long)blockIdx.x * 256 + tid;
+    auto one = [&](const uint4 raw, const uint4 rraw, long long ee, int qq) {
         float f[8], r[8];
         unpack8(raw, f);
-        if (rb) unpack8(*reinterpret_cast<const uint4*>(rb + e * 8), r);
+        if (rb) unpack8(rraw, r);
         // per-channel scale / shift / time-bias as 16-byte LDS reads (6 per chunk instead of 24 scalar ones)
         float sc[8], sh[8], tb[8];
-        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(s_scale + q * 8);
-        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(s_scale + q * 8 + 4);
-        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(s_shift + q * 8);
-        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(s_shift + q * 8 + 4);
-        *reinterpret_cast<float4*>(tb) = *reinterpret_cast<const float4*>(s_tb + q * 8);
-        *reinterpret_cast<float4*>(tb + 4) = *reinterpret_cast<const float4*>(s_tb + q * 8 + 4);
+        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(s_scale + qq * 8);
+        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(s_scale + qq * 8 + 4);
+        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(s_shift + qq * 8);
+        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(s_shift + qq * 8 + 4);
+        *reinterpret_cast<float4*>(tb) = *reinterpret_cast<const float4*>(s_tb + qq * 8);
+        *reinterpret_cast<float4*>(tb + 4) = *reinterpret_cast<const float4*>(s_tb + qq * 8 + 4);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float v = f[k] * sc[k] + sh[k];
@@ -202,7 +215,25 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const doub
             if (silu_post) v = silu_f(v);
             f[k] = v;
         }
-        *reinterpret_cast<uint4*>(yb + e * 8) = pack8(f);
+        *reinterpret_cast<uint4*>(yb + ee * 8) = pack8(f);
+    };
+    for (; e + (U - 1) * stride < total; e += U * stride) {
+        uint4 raw[U], rraw[U];
+        int qs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            raw[u] = *reinterpret_cast<const uint4*>(xb + (e + u * stride) * 8);
+            rraw[u] = rb ? *reinterpret_cast<const uint4*>(rb + (e + u * stride) * 8) : make_uint4(0, 0, 0, 0);
+            qs[u] = q;
+            q = (q + dq >= cpr) ? q + dq - cpr : q + dq;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(raw[u], rraw[u], e + u * stride, qs[u]);
+    }
+    for (; e < total; e += stride, q = (q + dq >= cpr) ? q + dq - cpr : q + dq) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(xb + e * 8);
+        const uint4 rraw = rb ? *reinterpret_cast<const uint4*>(rb + e * 8) : make_uint4(0, 0, 0, 0);
+        one(raw, rraw, e, q);
     }
 }
 

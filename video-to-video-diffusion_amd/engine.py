@@ -499,12 +499,8 @@ class Program:
         self.repack()
 
     def zero_gn_op(self):
-        lib, sptr, prog = self.lib, self.ctx.sptr, self
-
-        def run():
-            lib.memset_async(_ptr(prog._gn_sums), 0, prog._gn_sums.numel() * 8, sptr)
-
-        self._emit(run, "gn.zero")
+        """Kept for the program builders' call sites: ctsi_gn_finalize WRITES its (sum, sumsq) slots (one block per
+        (sample, group), fixed-order reduce), so the statistics buffer needs no per-evaluation zeroing any more."""
 
     def run(self):
         for op in self.ops:

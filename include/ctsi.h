@@ -90,6 +90,19 @@ typedef struct ctsi_conv_out {
     int act;             /* 0: none, 1: tanh (models/vae.py:203)                           */
     float* colsum;       /* optional: per-tile column sums for a following GroupNorm
                             ([2][ctsi_conv_plan_tiles()][cout_pad] floats), or NULL       */
+    /* optional fused ResBlock tail (models/unet3d.py:130-133, `self.activation(h + self.residual_conv(x))` with h =
+     * GroupNorm(conv2 output)): when gn_x != NULL the conv result r is not stored as is but
+     *     y = silu?( gn(gn_x) * gamma + beta + r ),   gn statistics from gn_sums (as ctsi_gn_apply reads them),
+     * so the residual tensor never goes to HBM.  mode 0 only, no colsum, no act; gn_x has y's shape and channel
+     * stride and may alias y (in place).  The gather-GEMM kernel implements it (1x1x1 residual convs).           */
+    const void* gn_x;        /* bf16 NDHWC, channel stride cout_stride, offset c_off                              */
+    const double* gn_sums;   /* [n][groups][2] fp64 (sum, sumsq) of gn_x                                          */
+    const float* gn_gamma;
+    const float* gn_beta;
+    int gn_groups;
+    float gn_eps;
+    long long gn_count;      /* elements per (sample, group) the statistics were taken over                       */
+    int gn_silu;             /* 1: SiLU after the add                                                             */
 } ctsi_conv_out;
 
 int ctsi_conv_plan_create(ctsi_conv_plan** plan, const ctsi_conv_desc* desc);
@@ -304,6 +317,33 @@ int ctsi_event_create(ctsi_event** ev);
 int ctsi_event_record(ctsi_event* ev, void* stream);
 int ctsi_event_elapsed_ms(ctsi_event* start, ctsi_event* stop, float* ms);
 void ctsi_event_destroy(ctsi_event* ev);
+
+/* depth-sharding collectives (RCCL over xGMI, one process per GPU) --------------------------- *
+ * a volume's depth is cut into `world` slabs; before a depth-3 conv a slab needs one boundary
+ * slice of each depth neighbour (models/unet3d.py:56,96,204-207,218-221; models/vae.py:27,65-69,86-90), GroupNorm needs
+ * (sum, sumsq) over the whole depth (unet3d.py:59,97,151,329) and TemporalAttention the depth sum.  Each call below is
+ * ONE sync point on `stream` (one RCCL group) and is stream-capture safe.  RCCL is bound at run time (dlopen; a librccl
+ * already in the process is reused).
+ *   host protocol: rank 0 calls ctsi_comm_unique_id, the 128 bytes are broadcast by the host (torch.distributed, MPI, a
+ *   file ...), every rank calls ctsi_comm_init with the current HIP device set.                                        */
+typedef struct ctsi_comm ctsi_comm;
+int ctsi_comm_unique_id(void* id128);
+/* world == 1 with id128 == NULL: no RCCL at all (every exchange degenerates to the volume-end zero fill). */
+int ctsi_comm_init(ctsi_comm** comm, const void* id128, int rank, int world);
+void ctsi_comm_destroy(ctsi_comm* comm);
+int ctsi_comm_rank(const ctsi_comm* comm);
+int ctsi_comm_world(const ctsi_comm* comm);
+/* lo_halo <- rank-1's hi_own, hi_halo <- rank+1's lo_own (`bytes` each; zeros at the volume's ends). */
+int ctsi_halo_exchange(ctsi_comm* comm, const void* lo_own, const void* hi_own, void* lo_halo, void* hi_halo,
+                       size_t bytes, void* stream);
+/* the same exchange plus, in the same sync point, sums[nsums] (fp64) and f32[nf32] summed over all ranks in place
+ * (GroupNorm statistics travel with the boundary slices of the tensor they normalise); any part may be absent. */
+int ctsi_halo_exchange_reduce(ctsi_comm* comm, const void* lo_own, const void* hi_own, void* lo_halo, void* hi_halo,
+                              size_t bytes, double* sums, int nsums, float* f32, long long nf32, void* stream);
+/* GroupNorm statistics (and optionally the TemporalAttention depth sum, fp32) summed over all ranks in place. */
+int ctsi_gn_allreduce(ctsi_comm* comm, double* sums, int nsums, float* f32, long long nf32, void* stream);
+/* recv = concatenation over ranks of `bytes` from each rank's send (result gather along depth). */
+int ctsi_comm_allgather(ctsi_comm* comm, const void* send, void* recv, size_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,9 @@ def test_conv_plan_geometry_and_flops(lib):
     assert abs(lib.conv_plan_flops(p) / 1e9 - 2087.4) < 0.5
     lib.conv_plan_destroy(p)
     p = _plan(lib, c1=128, cout=8)
-    assert lib.conv_plan_cout_pad(p) == 32
+    assert lib.conv_plan_cout_pad(p) == 16                       # few-cout head: conv3_head.hip, 2x4x16 tile x 16 couts
+    lib.conv_plan_config(p, C.byref(bm), C.byref(bn), C.byref(mode))
+    assert (bm.value, bn.value, mode.value) == (128, 16, 8)
     lib.conv_plan_destroy(p)
 
 

@@ -58,6 +58,14 @@ struct ConvKParams {
     int tap_margin[4];  // -min(tapdelta) per class (>= 0): makes every buffer soffset non-negative
     int ad_min[4];      // min depth tap offset per class
     int dbg;  // timing-only ablation bits (0 in production)
+    // fused ResBlock tail (ctsi_conv_out.gn_x): y = silu?(gn(gn_x) + conv result)
+    const bf16_t* gn_x;
+    const double* gn_sums;
+    const float* gn_gamma;
+    const float* gn_beta;
+    int gn_groups, gn_silu;
+    float gn_eps;
+    double gn_count;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -495,6 +503,24 @@ conv_gather_mfma_kernel(const ConvKParams p) {
             }
         }
     }
+    if (p.gn_x != nullptr && tid < BN) {
+        // fused ResBlock tail: per-channel scale / shift of this n-tile from the fp64 group statistics (as gn_apply_kernel
+        // computes them); the column-sum scratch is free (fused launches never emit column sums)
+        const int co = n0 + tid;
+        float sc = 0.0f, sh = 0.0f;
+        if (co < p.Cout) {
+            const int cpg = p.Cout / p.gn_groups, g = co / cpg;
+            const double* sm = p.gn_sums + ((long long)nb * p.gn_groups + g) * 2;
+            const double mean = sm[0] / p.gn_count;
+            double var = sm[1] / p.gn_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+            sc = p.gn_gamma[co] * rstd;
+            sh = p.gn_beta[co] - (float)mean * sc;
+        }
+        s_cs[tid] = sc;
+        s_cs[BN + tid] = sh;
+    }
     __syncthreads();
     if (p.colsum != nullptr && tid < BN) {
         float t1 = 0.0f, t2 = 0.0f;
@@ -510,14 +536,57 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     }
     if (p.out_mode == 0) {
         constexpr int CPR = BN / 8;  // 16-B chunks per row
+        constexpr int ITER = (BM * CPR) / NTH;
+        static_assert((BM * CPR) % NTH == 0, "store loop assumes whole iterations");
         bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
-        for (int c = tid; c < BM * CPR; c += NTH) {
-            const int row = c / CPR, cc = c - row * CPR;
-            const long long off = s_rowoff[row];
-            const int co = n0 + cc * 8;
-            if (off >= 0 && co < p.Cout && !(p.dbg & 1)) {
-                const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + cc * 8);
-                *reinterpret_cast<uint4*>(y + off + co) = v;
+        if (p.gn_x != nullptr) {
+            // fused ResBlock tail: all of this thread's 16-byte pieces of the normalised tensor are requested up front
+            // (ITER independent loads in flight), then combined with the staged conv result
+            uint4 hreg[ITER];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int c = tid + it * NTH;
+                const int row = c / CPR, cc = c - row * CPR;
+                const long long off = s_rowoff[row];
+                const int co = n0 + cc * 8;
+                hreg[it] = (off >= 0 && co < p.Cout) ? *reinterpret_cast<const uint4*>(p.gn_x + off + co)
+                                                     : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int c = tid + it * NTH;
+                const int row = c / CPR, cc = c - row * CPR;
+                const long long off = s_rowoff[row];
+                const int co = n0 + cc * 8;
+                if (off >= 0 && co < p.Cout) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + cc * 8);
+                    const uint4 h = hreg[it];
+                    const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, rw[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t ow[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ch = cc * 8 + 2 * k;
+                        float a = __uint_as_float(hw[k] << 16) * s_cs[ch] + s_cs[BN + ch] + __uint_as_float(rw[k] << 16);
+                        float b = __uint_as_float(hw[k] & 0xffff0000u) * s_cs[ch + 1] + s_cs[BN + ch + 1] +
+                                  __uint_as_float(rw[k] & 0xffff0000u);
+                        if (p.gn_silu) {
+                            a = silu_f(a);
+                            b = silu_f(b);
+                        }
+                        ow[k] = pack_bf16x2(a, b);
+                    }
+                    *reinterpret_cast<uint4*>(y + off + co) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                }
+            }
+        } else {
+            for (int c = tid; c < BM * CPR; c += NTH) {
+                const int row = c / CPR, cc = c - row * CPR;
+                const long long off = s_rowoff[row];
+                const int co = n0 + cc * 8;
+                if (off >= 0 && co < p.Cout && !(p.dbg & 1)) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + cc * 8);
+                    *reinterpret_cast<uint4*>(y + off + co) = v;
+                }
             }
         }
     }
@@ -984,6 +1053,13 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
                        "ctsi_conv_fwd: bf16 output needs cout, cout_stride, c_off multiples of 8 "
                        "(cout=%d stride=%d off=%d)", p->d.cout, o->cout_stride, o->c_off);
     }
+    if (o->gn_x != nullptr) {
+        CTSI_CHECK_ARG(!p->halo3 && o->mode == 0 && o->act == 0 && o->colsum == nullptr && p->nclass == 1,
+                       "ctsi_conv_fwd: the fused GroupNorm tail needs a gather-kernel plan, bf16 output, no act / colsum");
+        CTSI_CHECK_ARG(o->gn_sums && o->gn_gamma && o->gn_beta && o->gn_groups > 0 && p->d.cout % o->gn_groups == 0 &&
+                           o->gn_count > 0,
+                       "ctsi_conv_fwd: bad fused GroupNorm arguments (groups=%d, cout=%d)", o->gn_groups, p->d.cout);
+    }
     if (p->halo3 && (p->halo3 == 6 || (o->mode == 0 && o->act == 0))) {
         Conv3HaloParams h;
         memset(&h, 0, sizeof(h));
@@ -1056,6 +1132,14 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         static const char* dbgf = getenv("CTSI_DEBUG_FLAGS");
         k.dbg = dbgf ? atoi(dbgf) : 0;
     }
+    k.gn_x = (const bf16_t*)o->gn_x;
+    k.gn_sums = o->gn_sums;
+    k.gn_gamma = o->gn_gamma;
+    k.gn_beta = o->gn_beta;
+    k.gn_groups = o->gn_groups;
+    k.gn_silu = o->gn_silu;
+    k.gn_eps = o->gn_eps;
+    k.gn_count = (double)o->gn_count;
     k.dshift = p->dshift;
     memcpy(k.tap_margin, p->tap_margin, sizeof(k.tap_margin));
     memcpy(k.ad_min, p->ad_min, sizeof(k.ad_min));

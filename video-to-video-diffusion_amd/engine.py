@@ -242,9 +242,11 @@ class Program:
     def conv(self, name: str, weight_fn, bias_fn, x1: Act, x2: Optional[Act], *, transposed=False,
              k=(3, 3, 3), s=(1, 1), p=(1, 1, 1), cout: int, cin_w: Optional[int] = None,
              out: Optional[Act] = None, want_stats=False, f32_out: Optional[torch.Tensor] = None,
-             f32_strides: Optional[Sequence[int]] = None, act: int = 0):
+             f32_strides: Optional[Sequence[int]] = None, act: int = 0, fuse_gn=None):
         """Emit one convolution.  weight_fn/bias_fn return the *current* fp32 parameter tensors
-        (possibly derived, e.g. scaled or pre-multiplied).  Returns (out_act, stats_handle)."""
+        (possibly derived, e.g. scaled or pre-multiplied).  Returns (out_act, stats_handle).
+        `fuse_gn` = (h: Act, slot, gn: nn.GroupNorm, silu: bool): the epilogue stores silu?(gn(h) + conv result)
+        instead of the conv result (ctsi_conv_out.gn_x; h may be the output buffer itself)."""
         lib = self.lib
         deep = k[0] > 1 and x1.halo == 1   # depth taps read the halo slices: "valid" conv along depth
         if x1.halo and x1.n != 1:
@@ -304,14 +306,30 @@ class Program:
             co.c_off = 0
             out_act = out
         co.act = act
+        if fuse_gn is not None:
+            gh, gslot, gmod, gsilu = fuse_gn
+            if f32_out is not None or want_stats or (gh.n, gh.c, gh.d, gh.h, gh.w) != (x1.n, cout, do, ho, wo):
+                raise CtsiError("internal: fused GroupNorm tail needs a bf16 output of the normalised tensor's shape")
+            ggamma = self.dev_f32(lambda: gmod.weight)
+            gbeta = self.dev_f32(lambda: gmod.bias)
+            d_stat = gh.d * (self.shard.world if (self.shard is not None and gh.halo) else 1)
+            co.gn_x = gh.ip.value
+            co.gn_gamma, co.gn_beta = ggamma.data_ptr(), gbeta.data_ptr()
+            co.gn_groups, co.gn_eps = gmod.num_groups, float(gmod.eps)
+            co.gn_count = (cout // gmod.num_groups) * d_stat * gh.h * gh.w
+            co.gn_silu = int(gsilu)
         self.keep.append(co)
         x1p = x1.fp if deep else x1.ip
         x2p = C.c_void_p(0) if x2 is None else (x2.fp if deep else x2.ip)
         wp, bp = _ptr(packed), _ptr(bias)
         prog = self
 
+        gn_slot = fuse_gn[1] if fuse_gn is not None else None
+
         def run():
             co.colsum = prog._colsum.data_ptr() if want_stats else 0
+            if gn_slot is not None:
+                co.gn_sums = prog._gn_sums.data_ptr() + gn_slot * 8
             lib.conv_fwd(plan, x1p, x2p, wp, bp, C.byref(co), sptr)
 
         bm, bn, mode = C.c_int(), C.c_int(), C.c_int()
@@ -393,14 +411,9 @@ class Program:
         """ResBlock3D of the U-Net (models/unet3d.py:116-133); `skip` is the second half of a
         channel concatenation feeding the block (never materialised)."""
         cout = m.conv1.conv.out_channels
-        if isinstance(m.residual_conv, nn.Identity):
-            if skip is not None:
-                raise CtsiError("identity residual with a concatenated input")
-            r, own_r = x, False
-        else:
-            r, _ = self.conv("res1x1", lambda: m.residual_conv.weight, lambda: m.residual_conv.bias, x, skip,
-                             k=(1, 1, 1), p=(0, 0, 0), cout=cout)
-            own_r = True
+        has_res_conv = not isinstance(m.residual_conv, nn.Identity)
+        if not has_res_conv and skip is not None:
+            raise CtsiError("identity residual with a concatenated input")
         c1, st = self.conv("rb.conv1", lambda: m.conv1.conv.weight, lambda: m.conv1.conv.bias, x, skip,
                            cout=cout, want_stats=True)
         slot = self.gn_finalize(c1, m.conv1.norm.num_groups, st)
@@ -410,9 +423,18 @@ class Program:
                            want_stats=True)
         self.release(h1)
         slot = self.gn_finalize(c2, m.conv2[1].num_groups, st)
-        out = self.gn_apply(c2, slot, m.conv2[1], silu_pre=False, residual=r, silu_post=True, out=c2)
-        if own_r:
+        if not has_res_conv:
+            return self.gn_apply(c2, slot, m.conv2[1], silu_pre=False, residual=x, silu_post=True, out=c2)
+        if os.environ.get("CTSI_NO_FUSE_RES"):   # tuning / test aid: residual conv and GroupNorm tail as two launches
+            r, _ = self.conv("res1x1", lambda: m.residual_conv.weight, lambda: m.residual_conv.bias, x, skip,
+                             k=(1, 1, 1), p=(0, 0, 0), cout=cout)
+            out = self.gn_apply(c2, slot, m.conv2[1], silu_pre=False, residual=r, silu_post=True, out=c2)
             self.release(r)
+            return out
+        # block tail with a 1x1x1 residual conv: out = silu(gn(c2) + W_r [x | skip] + b_r) in ONE launch -- the conv's
+        # epilogue applies the GroupNorm of c2 and the activation, so the residual tensor never goes to HBM
+        out, _ = self.conv("res1x1+gn", lambda: m.residual_conv.weight, lambda: m.residual_conv.bias, x, skip,
+                           k=(1, 1, 1), p=(0, 0, 0), cout=cout, out=c2, fuse_gn=(c2, slot, m.conv2[1], True))
         return out
 
     def attention(self, m, x: Act, mode: str = "fast") -> Act:

@@ -44,6 +44,8 @@ class ConvOut(C.Structure):
         ("sh", C.c_longlong), ("sw", C.c_longlong),
         ("act", C.c_int),
         ("colsum", C.c_void_p),
+        ("gn_x", C.c_void_p), ("gn_sums", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
+        ("gn_groups", C.c_int), ("gn_eps", C.c_float), ("gn_count", C.c_longlong), ("gn_silu", C.c_int),
     ]
 
 
@@ -122,6 +124,15 @@ SIGNATURES = {
     "ctsi_blend_normalize": (_i, [_vp, _vp, _ll, _vp], True),
     "ctsi_slice_metrics_workspace_doubles": (_sz, [_i, _i, _i, _i, _i], False),
     "ctsi_slice_metrics": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], True),
+    "ctsi_comm_unique_id": (_i, [_vp], True),
+    "ctsi_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i], True),
+    "ctsi_comm_destroy": (None, [_vp], False),
+    "ctsi_comm_rank": (_i, [_vp], False),
+    "ctsi_comm_world": (_i, [_vp], False),
+    "ctsi_halo_exchange": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp], True),
+    "ctsi_halo_exchange_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _ll, _vp], True),
+    "ctsi_gn_allreduce": (_i, [_vp, _vp, _i, _vp, _ll, _vp], True),
+    "ctsi_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp], True),
     "ctsi_memset_async": (_i, [_vp, _i, _sz, _vp], True),
     "ctsi_graph_begin_capture": (_i, [_vp], True),
     "ctsi_graph_end_capture": (_i, [_vp, C.POINTER(_vp)], True),

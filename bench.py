@@ -96,8 +96,9 @@ def cpu_baseline(threads, latent_hw, depth):
 
 
 def bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist):
-    """Config 4: one 8->48 @512^2 volume, depth slab of 48/world slices per GPU, halo exchange + statistics
-    all-reduce over RCCL between kernels (eager launches: collectives are not captured)."""
+    """Config 4: one 8->48 @512^2 volume, depth slab of 48/world slices per GPU.  64 sync points per step (RCCL through the
+    C ABI, csrc/comm.hip): GroupNorm statistics travel with the boundary slices of the tensor they normalise.  Eager
+    launches by default; CTSI_SHARD_CAPTURE=1 captures kernels AND collectives into one hipGraph per step."""
     P = importlib.import_module("video-to-video-diffusion_amd.parallel")
     L = model.vae.latent_dim
     d, h, w = args.depth_out, args.hw // 4, args.hw // 4
@@ -108,7 +109,9 @@ def bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist):
     t_desc = [int(t) for t in pkg.DDIMSampler(model.diffusion, model.unet)._get_timesteps(args.ddim_steps)]
     total = args.warmup + args.steps
     reps = (total + len(t_desc) - 1) // len(t_desc) + 1
-    comm = P.DistComm() if world > 1 else P.LocalComm(1)
+    # RCCL issued by libctsi on the engine stream (C ABI); CTSI_SHARD_CAPTURE=1 replays the step as one hipGraph
+    comm = P.RcclComm.from_process_group() if world > 1 else P.RcclComm.single()
+    capture = os.environ.get("CTSI_SHARD_CAPTURE") == "1"
     spec = P.ShardSpec(rank, world, comm, d)
     with ctx.scope():
         prog = E.UNetProgram(ctx, model.unet, 1, spec.depth_local, h, w, max_rows=len(t_desc) * reps, shard=spec)
@@ -116,8 +119,12 @@ def bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist):
         prog.load_latents(z_T, cond)
         coef = S.ddim_coef_rows(model.diffusion.alphas_cumprod, t_desc, 0.0).repeat(reps, 1)
         prog.set_schedule([t for _ in range(reps) for t in t_desc], coef.to(dev))
+        if capture:
+            prog.capture()
+            prog.step_ptr.zero_()
+        step = prog.launch if capture else prog.run
         for _ in range(args.warmup):
-            prog.run()
+            step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -125,7 +132,7 @@ def bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist):
     t0 = time.perf_counter()
     with ctx.scope():
         for _ in range(args.steps):
-            prog.run()
+            step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -144,8 +151,9 @@ def bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"DDIM-{args.ddim_steps} step on ONE latent {list(shape)} depth-sharded "
-                                   f"{spec.depth_local} slices/GPU, RCCL halo exchange + GroupNorm/attention all-reduce",
-                       "parallelism": f"depth-shard{world}", "collectives_per_step": ncomm, "finite_outputs": finite},
+                                   f"{spec.depth_local} slices/GPU, RCCL: GroupNorm statistics travel with the boundary slices (one ncclGroup per sync point)",
+                       "parallelism": f"depth-shard{world}", "sync_points_per_step": ncomm, "captured": capture,
+                       "finite_outputs": finite},
             "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.destroy_process_group()

@@ -48,6 +48,18 @@ def _worker(rank, world, port, out_dir):
         comm.all_reduce(rank, sums)
         tot = sum(range(1, world + 1))
         assert sums.tolist() == [float(tot), 10.0 * tot]
+        # the coalesced sync point of the sharded programs: boundary slices + fp64 statistics + fp32 depth sum together
+        buf2 = torch.full(((dl + 2), H * W * C), -1.0).to(torch.bfloat16)
+        buf2[1:dl + 1] = (2.0 * full[slab.start:slab.stop]).to(torch.bfloat16)
+        f2 = buf2.reshape(-1)
+        sums2 = torch.tensor([1.5 * (rank + 1), -2.0 * (rank + 1)], dtype=torch.float64)
+        dsum = torch.full((5,), float(rank + 1))
+        comm.exchange(rank, f2[se:2 * se], f2[dl * se:(dl + 1) * se], f2[0:se], f2[(dl + 1) * se:(dl + 2) * se],
+                      sums=sums2, f32=dsum)
+        assert torch.equal(buf2.float(), (2.0 * want).to(torch.bfloat16).float()), rank
+        assert sums2.tolist() == [1.5 * tot, -2.0 * tot] and dsum.tolist() == [float(tot)] * 5
+        comm.exchange(rank, None, None, None, None, sums=sums2)         # statistics only
+        assert sums2.tolist() == [1.5 * tot * world, -2.0 * tot * world]
         # result gather along depth
         vol = full.reshape(1, 1, D, H * W, C)
         got = comm.gather_depth(rank, vol[:, :, slab.start:slab.stop].clone())
@@ -132,3 +144,12 @@ def test_local_comm_matches_dist_semantics():
     for r, v in enumerate(vals):
         comm.all_reduce(r, v)
     assert [v.item() for v in vals] == [3.0, 3.0, 3.0]
+    # coalesced sync point: slices + fp64 statistics + fp32 buffer in one call
+    sums = [torch.tensor([1.0 + r, 2.0], dtype=torch.float64) for r in range(world)]
+    f32 = [torch.full((3,), float(r)) for r in range(world)]
+    for r, b in enumerate(bufs):
+        b[0:se] = -7.0
+        b[3 * se:] = -7.0
+        comm.exchange(r, b[se:2 * se], b[2 * se:3 * se], b[0:se], b[3 * se:4 * se], sums=sums[r], f32=f32[r])
+    assert torch.equal(bufs[1][0:se], bufs[0][2 * se:3 * se]) and torch.equal(bufs[0][0:se], torch.zeros(se))
+    assert all(s_.tolist() == [6.0, 6.0] for s_ in sums) and all(f.tolist() == [3.0] * 3 for f in f32)

@@ -19,7 +19,13 @@ def enable_depth_sharding(model, group=None):
     """Shard every following sampling run depth-wise over the ranks of `group` (torch.distributed must be
     initialised, one process per GPU; backend "nccl" is RCCL on ROCm).  `model` is a
     VideoToVideoDiffusion (U-Net loop and VAE decode are sharded), a UNet3D or a VideoVAE."""
-    comm = parallel.DistComm(group)
+    import torch.distributed as dist
+    # GPU ranks: RCCL issued by libctsi on the engine stream (C ABI, capture-safe); anything else (the gloo CPU tests of
+    # the host logic): the same sync points over torch.distributed
+    if dist.is_initialized() and dist.get_backend(group) == "nccl":
+        comm = parallel.RcclComm.from_process_group(group)
+    else:
+        comm = parallel.DistComm(group)
     for m in (getattr(model, "unet", None), getattr(model, "vae", None), model):
         if m is not None and type(m).__name__ in ("UNet3D", "SliceInterpolationVAE"):
             m.depth_shard_comm = comm

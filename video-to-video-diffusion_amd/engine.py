@@ -159,31 +159,80 @@ class Program:
         return Act(self.pool.get(n * c * (d + 2 * halo) * h * w, torch.bfloat16), n, c, d, h, w, halo)
 
     # ---- depth-sharding collectives (no-ops in single-GPU programs) -----------------------------------
+    # A sharded program is ~64 sync points per U-Net evaluation (was 119): the GroupNorm statistics of a tensor travel in
+    # the SAME sync point as the raw boundary slices of that tensor (`sync_stats_and_halos`); the normalisation is then
+    # applied to the own slices AND the received halo slices (`ext` ranges below), so the tensor a depth-3 conv consumes
+    # never needs a second exchange.  Only tensors no GroupNorm follows (conv_in / Downsample / Upsample outputs, the
+    # sampler's updated input) use the plain `halo_exchange`.
+    def _slices(self, a: Act):
+        se, d = a.slice_elems, a.d
+        buf = a.t
+        return buf[se:2 * se], buf[d * se:(d + 1) * se], buf[0:se], buf[(d + 1) * se:(d + 2) * se]
+
     def halo_exchange(self, a: Act):
         """Refresh a's two halo slices from the depth neighbours (zeros at the volume's ends)."""
         if self.shard is None or not a.halo or not a.dirty:
             return
         a.dirty = False
-        se = a.slice_elems
-        buf, d = a.t, a.d
-        views = dict(lo_halo=buf[0:se], lo_own=buf[se:2 * se], hi_own=buf[d * se:(d + 1) * se],
-                     hi_halo=buf[(d + 1) * se:(d + 2) * se])
-        spec, stream = self.shard, self.ctx.stream
+        lo_own, hi_own, lo_halo, hi_halo = self._slices(a)
+        spec, sptr = self.shard, self.ctx.sptr
 
         def run():
-            spec.comm.exchange(spec.rank, views["lo_own"], views["hi_own"], views["lo_halo"], views["hi_halo"])
+            spec.comm.exchange(spec.rank, lo_own, hi_own, lo_halo, hi_halo, sptr=sptr)
 
         self._emit(run, "halo.exchange", 0.0, "comm")
 
-    def all_reduce(self, t: torch.Tensor, name: str):
+    def sync_stats_and_halos(self, a: Optional[Act], slot: Optional[int], nvals: int = 0,
+                             f32: Optional[torch.Tensor] = None, name: str = "gn.sync"):
+        """ONE sync point: all-reduce of the fp64 statistics slot (and of `f32`, the attention depth sum) together with
+        the neighbour exchange of a's raw boundary slices (a = None: statistics only)."""
         if self.shard is None:
             return
-        spec = self.shard
+        spec, sptr, prog = self.shard, self.ctx.sptr, self
+        sl = self._slices(a) if (a is not None and a.halo) else (None, None, None, None)
+        if a is not None and a.halo:
+            a.dirty = False
+        holder = {}
 
         def run():
-            spec.comm.all_reduce(spec.rank, t)
+            sums = None
+            if slot is not None:
+                if "v" not in holder:
+                    holder["v"] = prog._gn_sums[slot:slot + nvals]
+                sums = holder["v"]
+            spec.comm.exchange(spec.rank, sl[0], sl[1], sl[2], sl[3], sums=sums, f32=f32, sptr=sptr)
 
         self._emit(run, name, 0.0, "comm")
+
+    def ext(self, a: Act) -> Tuple[int, int]:
+        """(slices below the own ones, total depth) of the range an elementwise op covers on `a`: the own slices plus
+        the halo slices that exist -- none on a single GPU, none towards a volume end (those stay zero: the conv's
+        zero padding)."""
+        if self.shard is None or not a.halo:
+            return 0, a.d
+        lo = 1 if self.shard.rank > 0 else 0
+        hi = 1 if self.shard.rank < self.shard.world - 1 else 0
+        return lo, a.d + lo + hi
+
+    def ext_ptr(self, a: Act, lo: int) -> C.c_void_p:
+        return C.c_void_p(a.ip.value - lo * a.slice_elems * 2)
+
+    def zero_end_halos(self, a: Act):
+        """A NEW buffer written over its `ext` range: the halo slice towards a volume end is not covered and must read
+        as zeros (emitted on every rank -- the lock-step test driver needs equal op lists; a no-op on inner ranks)."""
+        if self.shard is None or not a.halo:
+            return
+        spec, lib, sptr = self.shard, self.lib, self.ctx.sptr
+        _, _, lo_halo, hi_halo = self._slices(a)
+        nbytes = a.slice_elems * 2
+
+        def run():
+            if spec.rank == 0:
+                lib.memset_async(_ptr(lo_halo), 0, nbytes, sptr)
+            if spec.rank == spec.world - 1:
+                lib.memset_async(_ptr(hi_halo), 0, nbytes, sptr)
+
+        self._emit(run, "halo.zero_ends")
 
     def release(self, a: Act):
         self.pool.put(a.t)
@@ -242,7 +291,7 @@ class Program:
     def conv(self, name: str, weight_fn, bias_fn, x1: Act, x2: Optional[Act], *, transposed=False,
              k=(3, 3, 3), s=(1, 1), p=(1, 1, 1), cout: int, cin_w: Optional[int] = None,
              out: Optional[Act] = None, want_stats=False, f32_out: Optional[torch.Tensor] = None,
-             f32_strides: Optional[Sequence[int]] = None, act: int = 0, fuse_gn=None):
+             f32_strides: Optional[Sequence[int]] = None, act: int = 0, fuse_gn=None, ext_out: bool = False):
         """Emit one convolution.  weight_fn/bias_fn return the *current* fp32 parameter tensors
         (possibly derived, e.g. scaled or pre-multiplied).  Returns (out_act, stats_handle).
         `fuse_gn` = (h: Act, slot, gn: nn.GroupNorm, silu: bool): the epilogue stores silu?(gn(h) + conv result)
@@ -250,12 +299,20 @@ class Program:
         lib = self.lib
         deep = k[0] > 1 and x1.halo == 1   # depth taps read the halo slices: "valid" conv along depth
         if x1.halo and x1.n != 1:
-            raise CtsiError("depth-sharded programs support one volume per rank")
+            raise CtsiError("a depth-sharded program holds one volume (batches run volume by volume, see "
+                            "sampler.run_sampler_sharded)")
         if deep:
             self.halo_exchange(x1)
             if x2 is not None:
                 self.halo_exchange(x2)
-        di = x1.d + 2 if deep else x1.d
+        # a pointwise conv whose inputs carry valid halo slices may cover them too (`ext_out`): its output then has valid
+        # halos without an exchange of its own (the fused residual tail of a sharded ResBlock)
+        ext_lo, ext_d = (0, x1.d)
+        if ext_out:
+            if deep or x1.dirty or (x2 is not None and x2.dirty):
+                raise CtsiError("internal: ext_out needs a pointwise conv over inputs with valid halo slices")
+            ext_lo, ext_d = self.ext(x1)
+        di = x1.d + 2 if deep else ext_d
         desc = ConvDesc(int(transposed), k[0], k[1], k[2], s[0], s[1], p[0], p[1], p[2], x1.n, x1.c,
                         0 if x2 is None else x2.c, cout, di, x1.h, x1.w, 1 if deep else 0)
         plan = C.c_void_p()
@@ -298,9 +355,9 @@ class Program:
             out_act = None
         else:
             if out is None:
-                out = self.act(x1.n, cout, do, ho, wo, halo=x1.halo)
-            out.dirty = True
-            co.y = out.ip.value
+                out = self.act(x1.n, cout, do - (ext_d - x1.d), ho, wo, halo=x1.halo)
+            out.dirty = not ext_out
+            co.y = self.ext_ptr(out, ext_lo).value
             co.mode = 0
             co.cout_stride = out.c
             co.c_off = 0
@@ -308,19 +365,19 @@ class Program:
         co.act = act
         if fuse_gn is not None:
             gh, gslot, gmod, gsilu = fuse_gn
-            if f32_out is not None or want_stats or (gh.n, gh.c, gh.d, gh.h, gh.w) != (x1.n, cout, do, ho, wo):
+            if f32_out is not None or want_stats or (gh.n, gh.c, gh.d, gh.h, gh.w) != (x1.n, cout, out.d, ho, wo):
                 raise CtsiError("internal: fused GroupNorm tail needs a bf16 output of the normalised tensor's shape")
             ggamma = self.dev_f32(lambda: gmod.weight)
             gbeta = self.dev_f32(lambda: gmod.bias)
             d_stat = gh.d * (self.shard.world if (self.shard is not None and gh.halo) else 1)
-            co.gn_x = gh.ip.value
+            co.gn_x = self.ext_ptr(gh, ext_lo).value
             co.gn_gamma, co.gn_beta = ggamma.data_ptr(), gbeta.data_ptr()
             co.gn_groups, co.gn_eps = gmod.num_groups, float(gmod.eps)
             co.gn_count = (cout // gmod.num_groups) * d_stat * gh.h * gh.w
             co.gn_silu = int(gsilu)
         self.keep.append(co)
-        x1p = x1.fp if deep else x1.ip
-        x2p = C.c_void_p(0) if x2 is None else (x2.fp if deep else x2.ip)
+        x1p = x1.fp if deep else self.ext_ptr(x1, ext_lo)
+        x2p = C.c_void_p(0) if x2 is None else (x2.fp if deep else self.ext_ptr(x2, ext_lo))
         wp, bp = _ptr(packed), _ptr(bias)
         prog = self
 
@@ -356,16 +413,8 @@ class Program:
                             groups, tps, nclass, sptr)
 
         self._emit(run, "gn.finalize")
-        if self.shard is not None:
-            nvals = x.n * groups * 2
-            holder = {}
-
-            def run_ar():
-                if "v" not in holder:
-                    holder["v"] = prog._gn_sums[slot:slot + nvals]
-                prog.shard.comm.all_reduce(prog.shard.rank, holder["v"])
-
-            self._emit(run_ar, "gn.allreduce", 0.0, "comm")
+        # depth-sharded programs: the slot holds this slab's sums until `sync_stats_and_halos` (emitted by the consumer:
+        # gn_apply / attention / the fused residual tail) all-reduces it together with the tensor's boundary slices
         return slot
 
     def gn_colsum(self, x: Act) -> dict:
@@ -383,26 +432,39 @@ class Program:
 
     def gn_apply(self, x: Act, slot: int, gn: nn.GroupNorm, *, silu_pre: bool, tbias=None,
                  tbias_off: int = 0, tbias_stride: int = 0, step_ptr: Optional[torch.Tensor] = None,
-                 residual: Optional[Act] = None, silu_post: bool = False, out: Optional[Act] = None) -> Act:
+                 residual: Optional[Act] = None, silu_post: bool = False, out: Optional[Act] = None,
+                 synced: bool = False) -> Act:
+        """y = [silu](gn(x)) [+ tbias] [+ residual] [silu].  Depth-sharded: first the sync point that all-reduces the
+        statistics and exchanges x's RAW boundary slices (unless `synced`: the caller already did), then the
+        normalisation over own + received halo slices -- y's halos are valid without an exchange of its own."""
         lib, sptr, prog = self.lib, self.ctx.sptr, self
+        if self.shard is not None and not synced:
+            self.sync_stats_and_halos(x if x.halo else None, slot, x.n * gn.num_groups * 2)
+        if residual is not None and self.shard is not None and residual.halo:
+            self.halo_exchange(residual)     # (already valid in the networks of this repo: a no-op)
+        lo, d_ext = self.ext(x)
         gamma = self.dev_f32(lambda: gn.weight)
         beta = self.dev_f32(lambda: gn.bias)
         self.track(gn.weight, gn.bias)
+        fresh = out is None
         if out is None:
             out = self.act(x.n, x.c, x.d, x.h, x.w, halo=x.halo)
-        out.dirty = True
-        xp, yp, gp, bp = x.ip, out.ip, _ptr(gamma), _ptr(beta)
+        out.dirty = bool(self.shard is not None and x.halo and x.dirty)
+        xp, yp, gp, bp = self.ext_ptr(x, lo), self.ext_ptr(out, lo), _ptr(gamma), _ptr(beta)
         tbp = C.c_void_p(0 if tbias is None else tbias.data_ptr() + tbias_off * 4)
         stp = _ptr(step_ptr)
-        rp = C.c_void_p(0) if residual is None else residual.ip
-        n, c, d, h, w, groups, eps = x.n, x.c, x.d, x.h, x.w, gn.num_groups, float(gn.eps)
-        d_stat = d * (self.shard.world if (self.shard is not None and x.halo) else 1)  # statistics span all ranks
+        rp = C.c_void_p(0) if residual is None else self.ext_ptr(residual, lo)
+        n, c, h, w, groups, eps = x.n, x.c, x.h, x.w, gn.num_groups, float(gn.eps)
+        d_stat = x.d * (self.shard.world if (self.shard is not None and x.halo) else 1)  # statistics span all ranks
+        d = d_ext
 
         def run():
             lib.gn_apply(xp, yp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, n, c, d, h, w, d_stat,
                          groups, eps, int(silu_pre), tbp, tbias_stride, stp, rp, int(silu_post), sptr)
 
         self._emit(run, "gn.apply")
+        if fresh:
+            self.zero_end_halos(out)
         return out
 
     # ---- U-Net blocks ------------------------------------------------------------------------------------
@@ -426,15 +488,25 @@ class Program:
         if not has_res_conv:
             return self.gn_apply(c2, slot, m.conv2[1], silu_pre=False, residual=x, silu_post=True, out=c2)
         if os.environ.get("CTSI_NO_FUSE_RES"):   # tuning / test aid: residual conv and GroupNorm tail as two launches
+            if self.shard is not None:
+                for a in (x, skip):
+                    if a is not None:
+                        self.halo_exchange(a)
             r, _ = self.conv("res1x1", lambda: m.residual_conv.weight, lambda: m.residual_conv.bias, x, skip,
-                             k=(1, 1, 1), p=(0, 0, 0), cout=cout)
+                             k=(1, 1, 1), p=(0, 0, 0), cout=cout, ext_out=self.shard is not None)
             out = self.gn_apply(c2, slot, m.conv2[1], silu_pre=False, residual=r, silu_post=True, out=c2)
             self.release(r)
             return out
         # block tail with a 1x1x1 residual conv: out = silu(gn(c2) + W_r [x | skip] + b_r) in ONE launch -- the conv's
         # epilogue applies the GroupNorm of c2 and the activation, so the residual tensor never goes to HBM
+        if self.shard is not None:
+            self.sync_stats_and_halos(c2, slot, c2.n * m.conv2[1].num_groups * 2)
+            for a in (x, skip):
+                if a is not None:
+                    self.halo_exchange(a)    # valid already (a no-op) for every block of the U-Net
         out, _ = self.conv("res1x1+gn", lambda: m.residual_conv.weight, lambda: m.residual_conv.bias, x, skip,
-                           k=(1, 1, 1), p=(0, 0, 0), cout=cout, out=c2, fuse_gn=(c2, slot, m.conv2[1], True))
+                           k=(1, 1, 1), p=(0, 0, 0), cout=cout, out=c2, fuse_gn=(c2, slot, m.conv2[1], True),
+                           ext_out=self.shard is not None)
         return out
 
     def attention(self, m, x: Act, mode: str = "fast") -> Act:
@@ -454,9 +526,11 @@ class Program:
             lib.attn_depthsum(xp, dsp, _ptr(prog._colsum), n, c, d, h, w, sptr)
 
         self._emit(run_ds, "attn.depthsum")
-        if world > 1:
-            self.all_reduce(depthsum, "attn.allreduce")
         slot = self.gn_finalize(x, m.norm.num_groups, dict(tps=tps, cpad=c, nclass=1))
+        if self.shard is not None and x.halo:
+            # one sync point: GroupNorm statistics (fp64) + the depth sum (fp32) over all ranks
+            self.sync_stats_and_halos(None, slot, n * m.norm.num_groups * 2, f32=depthsum, name="attn.sync")
+            self.halo_exchange(x)        # the block's input (valid already in this repo's networks: a no-op)
         gamma = self.dev_f32(lambda: m.norm.weight)
         beta = self.dev_f32(lambda: m.norm.bias)
         xs = self.act(n, c, 1, h, w, halo=0)
@@ -502,12 +576,16 @@ class Program:
             self._emit(run_rs, "attn.softmax_rowsum")
             self.release(qk)
         out = self.act(n, c, d, h, w, halo=x.halo)
-        pp, op_, rsp2 = pterm.ip, out.ip, _ptr(rowsum)
+        lo, d_ext = self.ext(x)          # x + P over own AND halo slices: P does not depend on depth
+        out.dirty = False
+        pp, op_, rsp2 = pterm.ip, self.ext_ptr(out, lo), _ptr(rowsum)
+        xep = self.ext_ptr(x, lo)
 
         def run_ba():
-            lib.attn_broadcast_add(xp, pp, rsp2, heads, op_, n, c, d, h, w, sptr)
+            lib.attn_broadcast_add(xep, pp, rsp2, heads, op_, n, c, d_ext, h, w, sptr)
 
         self._emit(run_ba, "attn.broadcast_add")
+        self.zero_end_halos(out)
         self.release(pterm)
         if rowsum is not None:
             self.pool.put(rowsum)

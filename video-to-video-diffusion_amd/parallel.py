@@ -58,8 +58,92 @@ def depth_slab(depth: int, rank: int, world: int) -> range:
 
 
 # ---- communicators ---------------------------------------------------------------------------------------------
+# One interface, three transports.  A call is ONE sync point of the sharded program:
+#     exchange(rank, lo_own, hi_own, lo_halo, hi_halo, sums=None, f32=None, sptr=None)
+#         lo_halo <- rank-1's hi_own, hi_halo <- rank+1's lo_own (zeros at the volume's two ends), and in the same sync
+#         point `sums` (fp64 GroupNorm statistics) / `f32` (TemporalAttention depth sum) are summed over all ranks in
+#         place.  Every part is optional (slices None = a pure all-reduce).
+#     gather_depth(rank, slab)  -> the full tensor, slabs concatenated along depth (dim 2)
+# `sptr` is the engine's HIP stream (only the RCCL transport needs it).
+class RcclComm:
+    """The C-ABI transport (csrc/comm.hip): RCCL calls issued by libctsi on the engine stream, one ncclGroup per sync
+    point, stream-capture safe.  The 128-byte RCCL unique id is created on rank 0 and broadcast through the
+    torch.distributed group the caller already has (any backend), so this works under torchrun as launched by
+    bench.py: `RcclComm.from_process_group()`."""
+    capturable = True
+
+    def __init__(self, handle, rank: int, world: int):
+        from .lib import get_lib
+        self.lib = get_lib()
+        self.handle = handle
+        self.rank, self.world = rank, world
+
+    @classmethod
+    def from_process_group(cls, group=None, device=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from .lib import get_lib
+        if not dist.is_initialized():
+            raise CtsiError("RcclComm.from_process_group needs an initialised torch.distributed process group")
+        lib = get_lib()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            lib.comm_unique_id(C.cast(buf, C.c_void_p))
+        on_gpu = dist.get_backend(group) == "nccl"
+        dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+        t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=dev if on_gpu else "cpu")
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        idb = (C.c_ubyte * 128)(*t.cpu().tolist())
+        handle = C.c_void_p()
+        lib.comm_init(C.byref(handle), C.cast(idb, C.c_void_p), rank, world)
+        return cls(handle, rank, world)
+
+    @classmethod
+    def single(cls, with_rccl: bool = False):
+        """World of one.  `with_rccl` builds a real one-rank RCCL communicator (exercises the binding on one GPU)."""
+        import ctypes as C
+        from .lib import get_lib
+        lib = get_lib()
+        handle = C.c_void_p()
+        if with_rccl:
+            buf = (C.c_ubyte * 128)()
+            lib.comm_unique_id(C.cast(buf, C.c_void_p))
+            lib.comm_init(C.byref(handle), C.cast(buf, C.c_void_p), 0, 1)
+        else:
+            lib.comm_init(C.byref(handle), None, 0, 1)
+        return cls(handle, 0, 1)
+
+    def exchange(self, rank, lo_own, hi_own, lo_halo, hi_halo, sums=None, f32=None, sptr=None):
+        import ctypes as C
+        p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+        nbytes = 0 if lo_own is None else lo_own.numel() * lo_own.element_size()
+        self.lib.halo_exchange_reduce(self.handle, p(lo_own), p(hi_own), p(lo_halo), p(hi_halo), nbytes, p(sums),
+                                      0 if sums is None else sums.numel(), p(f32), 0 if f32 is None else f32.numel(),
+                                      sptr)
+
+    def gather_depth(self, rank, slab, sptr=None):
+        import ctypes as C
+        slab = slab.contiguous()
+        out = torch.empty((self.world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
+        if sptr is None:
+            sptr = C.c_void_p(torch.cuda.current_stream(slab.device).cuda_stream)
+        self.lib.comm_allgather(self.handle, C.c_void_p(slab.data_ptr()), C.c_void_p(out.data_ptr()),
+                                slab.numel() * slab.element_size(), sptr)
+        return torch.cat([out[r] for r in range(self.world)], dim=2)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.comm_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class DistComm:
-    """Depth-sharding collectives over torch.distributed (RCCL on GPUs, gloo on CPU tensors)."""
+    """The same sync points over torch.distributed (gloo for the CPU tests of the host logic; also usable with the
+    nccl backend, uncaptured)."""
+    capturable = False
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -74,27 +158,30 @@ class DistComm:
     def _raw(t: torch.Tensor) -> torch.Tensor:
         return t.view(torch.int16) if t.dtype == torch.bfloat16 else t
 
-    def exchange(self, rank: int, lo_own, hi_own, lo_halo, hi_halo):
-        """lo_halo <- rank-1's hi_own, hi_halo <- rank+1's lo_own; zeros at the volume's two ends."""
+    def exchange(self, rank, lo_own, hi_own, lo_halo, hi_halo, sums=None, f32=None, sptr=None):
         dist, ops = self.dist, []
-        if rank > 0:
-            ops.append(dist.P2POp(dist.isend, self._raw(lo_own), rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, self._raw(lo_halo), rank - 1, self.group))
-        else:
-            lo_halo.zero_()
-        if rank < self.world - 1:
-            ops.append(dist.P2POp(dist.isend, self._raw(hi_own), rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, self._raw(hi_halo), rank + 1, self.group))
-        else:
-            hi_halo.zero_()
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        if lo_own is not None:
+            if rank > 0:
+                ops.append(dist.P2POp(dist.isend, self._raw(lo_own), rank - 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, self._raw(lo_halo), rank - 1, self.group))
+            else:
+                lo_halo.zero_()
+            if rank < self.world - 1:
+                ops.append(dist.P2POp(dist.isend, self._raw(hi_own), rank + 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, self._raw(hi_halo), rank + 1, self.group))
+            else:
+                hi_halo.zero_()
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        for t in (sums, f32):
+            if t is not None:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        for req in reqs:
+            req.wait()
 
     def all_reduce(self, rank: int, t: torch.Tensor):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
-    def gather_depth(self, rank: int, slab: torch.Tensor) -> torch.Tensor:
+    def gather_depth(self, rank: int, slab: torch.Tensor, sptr=None) -> torch.Tensor:
         outs = [torch.empty_like(slab) for _ in range(self.world)]
         self.dist.all_gather(outs, slab.contiguous(), group=self.group)
         return torch.cat(outs, dim=2)
@@ -103,6 +190,7 @@ class DistComm:
 class LocalComm:
     """`world` virtual ranks in one process, driven in lock-step (op i of rank 0, 1, ... then op i+1):
     each collective call parks its tensors; the last rank to arrive performs the exchange for all."""
+    capturable = False
 
     def __init__(self, world: int):
         self.world = world
@@ -115,31 +203,32 @@ class LocalComm:
         items, self._pending = sorted(self._pending, key=lambda it: it[0]), []
         return items
 
-    def exchange(self, rank: int, lo_own, hi_own, lo_halo, hi_halo):
-        items = self._arrive((rank, lo_own, hi_own, lo_halo, hi_halo))
+    def exchange(self, rank, lo_own, hi_own, lo_halo, hi_halo, sums=None, f32=None, sptr=None):
+        items = self._arrive((rank, lo_own, hi_own, lo_halo, hi_halo, sums, f32))
         if items is None:
             return
-        for r, (_, lo, hi, lo_h, hi_h) in enumerate(items):
-            if r > 0:
-                lo_h.copy_(items[r - 1][2])
-            else:
-                lo_h.zero_()
-            if r < self.world - 1:
-                hi_h.copy_(items[r + 1][1])
-            else:
-                hi_h.zero_()
+        if items[0][1] is not None:
+            for r, it in enumerate(items):      # (own and halo slices never alias: plain copies)
+                if r > 0:
+                    it[3].copy_(items[r - 1][2])
+                else:
+                    it[3].zero_()
+                if r < self.world - 1:
+                    it[4].copy_(items[r + 1][1])
+                else:
+                    it[4].zero_()
+        for k in (5, 6):
+            if items[0][k] is not None:
+                total = items[0][k].clone()
+                for it in items[1:]:
+                    total += it[k]
+                for it in items:
+                    it[k].copy_(total)
 
     def all_reduce(self, rank: int, t: torch.Tensor):
-        items = self._arrive((rank, t))
-        if items is None:
-            return
-        total = items[0][1].clone()
-        for _, other in items[1:]:
-            total += other
-        for _, dst in items:
-            dst.copy_(total)
+        self.exchange(rank, None, None, None, None, sums=t)
 
-    def gather_depth(self, rank: int, slab: torch.Tensor):
+    def gather_depth(self, rank: int, slab: torch.Tensor, sptr=None):
         items = self._arrive((rank, slab))
         if items is None:
             return None

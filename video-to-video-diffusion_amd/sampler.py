@@ -53,9 +53,13 @@ def ddim_coef_rows(alphas_cumprod: torch.Tensor, timesteps: Sequence[int], eta: 
 
 def run_sampler_sharded(diffusion, unet, shape, conditioning, ctx, z0, *, kind, t_desc, eta, noise_fn, comm,
                         trajectory=None):
-    """Depth-sharded reverse loop: this process owns depth slab `comm.rank` of the volume
-    (parallel.DistComm over RCCL).  Every rank passes the full conditioning / initial noise and gets
-    the full result back (all-gather along depth)."""
+    """Depth-sharded reverse loop: this process owns depth slab `comm.rank` of the volume (parallel.RcclComm: RCCL
+    issued by libctsi on the engine stream; parallel.DistComm under the gloo tests).  Every rank passes the full
+    conditioning / initial noise and gets the full result back (all-gather along depth).  A batch runs volume by
+    volume through the one-volume sharded program (every rank holds 1/world of ONE volume at a time).
+    With a capture-safe transport and CTSI_SHARD_CAPTURE=1 the step -- kernels AND collectives -- is replayed as one
+    hipGraph, like the single-GPU step."""
+    import os
     from .engine import cached_program
     from .parallel import ShardSpec
     n, L, d, h, w = [int(v) for v in shape]
@@ -63,28 +67,40 @@ def run_sampler_sharded(diffusion, unet, shape, conditioning, ctx, z0, *, kind, 
     dl = spec.depth_local
     with_noise = (kind == "ddpm") or eta > 0
     steps = len(t_desc)
+    capture = bool(getattr(comm, "capturable", False)) and os.environ.get("CTSI_SHARD_CAPTURE") == "1"
+    outs, trajs = [], [[] for _ in range(steps)]
     with ctx.scope():
-        key = ("sampler-shard", ctx.device.index, n, d, h, w, comm.rank, comm.world, kind, with_noise)
+        key = ("sampler-shard", ctx.device.index, 1, d, h, w, comm.rank, comm.world, kind, with_noise)
 
         def build():
-            prog = UNetProgram(ctx, unet, n, dl, h, w, (diffusion.timesteps + 1) * n, "fast", shard=spec)
+            prog = UNetProgram(ctx, unet, 1, dl, h, w, diffusion.timesteps + 1, "fast", shard=spec)
             prog.add_sampler_step(kind, with_noise)
             return prog
 
         prog = cached_program(unet, key, build)
-        prog.load_latents(z0, conditioning)
         coef = (ddim_coef_rows(diffusion.alphas_cumprod, t_desc, eta) if kind == "ddim"
                 else diffusion.ddpm_coef_rows(t_desc))
-        prog.set_schedule([int(t) for t in t_desc for _ in range(n)], coef.to(ctx.device))
         lo = comm.rank * dl
-        for i in range(steps):
-            if with_noise:
-                full = noise_fn(i, tuple(shape)) if noise_fn is not None else torch.randn(tuple(shape), device=ctx.device)
-                prog.noise.copy_(full[:, :, lo:lo + dl].to(ctx.device, torch.float32))
-            prog.run()
-            if trajectory is not None:
-                trajectory.append(comm.gather_depth(comm.rank, prog.z_ncdhw()))
-        return comm.gather_depth(comm.rank, prog.z_ncdhw())
+        noises = {}
+        for b in range(n):
+            prog.load_latents(z0[b:b + 1], conditioning[b:b + 1])
+            prog.set_schedule([int(t) for t in t_desc], coef.to(ctx.device))
+            if capture and prog.graph is None:
+                prog.capture()
+                prog.step_ptr.zero_()
+            for i in range(steps):
+                if with_noise:
+                    if i not in noises:   # one draw per step for the whole batch, as the unsharded loop makes it
+                        noises[i] = (noise_fn(i, tuple(shape)) if noise_fn is not None
+                                     else torch.randn(tuple(shape), device=ctx.device))
+                    prog.noise.copy_(noises[i][b:b + 1, :, lo:lo + dl].to(ctx.device, torch.float32))
+                prog.launch() if capture else prog.run()
+                if trajectory is not None:
+                    trajs[i].append(comm.gather_depth(comm.rank, prog.z_ncdhw()))
+            outs.append(comm.gather_depth(comm.rank, prog.z_ncdhw()))
+        if trajectory is not None:
+            trajectory.extend(torch.cat(t, dim=0) for t in trajs)
+        return torch.cat(outs, dim=0)
 
 
 def run_sampler(diffusion, model, shape, conditioning, device, *, kind: str, t_desc: Sequence[int],

@@ -134,9 +134,11 @@ class SliceInterpolationVAE(nn.Module):
             if comm is not None and comm.world > 1:
                 from .parallel import ShardSpec
                 spec = ShardSpec(comm.rank, comm.world, comm, d)
-                key = ("dec-shard", ctx.device.index, n, d, h, w, comm.rank, comm.world, float(self.scaling_factor))
-                prog = cached_program(self, key, lambda: VAEDecodeProgram(ctx, self, n, spec.depth_local, h, w,
+                key = ("dec-shard", ctx.device.index, 1, d, h, w, comm.rank, comm.world, float(self.scaling_factor))
+                prog = cached_program(self, key, lambda: VAEDecodeProgram(ctx, self, 1, spec.depth_local, h, w,
                                                                            shard=spec))
+                # a depth-sharded program holds one volume: a batch is decoded volume by volume
+                return torch.cat([prog(z[i:i + 1]) for i in range(n)], dim=0)
             else:
                 key = ("dec", ctx.device.index, n, d, h, w, float(self.scaling_factor))
                 prog = cached_program(self, key, lambda: VAEDecodeProgram(ctx, self, n, d, h, w))

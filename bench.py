@@ -40,6 +40,8 @@ LEGACY163_CFG = {  # the flat config behind the "163 M-param U-Net" of the refer
     'unet_attention_levels': [1, 2], 'unet_channel_mult': [1, 2, 4], 'unet_num_heads': 8, 'unet_time_embed_dim': 1024,
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0       # HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable with a float4 copy)
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")   # written by tools/pmc_traffic.py (records its commit)
 
 
 def parse():
@@ -328,15 +330,34 @@ def main():
                             "m4": "conv3_halo32_kernel (3x3x3 LDS halo tile 4x2x32, mfma_32x32x16_bf16)",
                             "m3": "conv3_halo_kernel (3x3x3 LDS halo tile 4x4x16, mfma_16x16x32_bf16)"}
             dom_name = kernel_names.get(dom_key.rsplit("_", 1)[-1], "conv_gather_mfma_kernel " + dom_key)
-            traffic = None
-            try:  # HBM bytes per launch from the last rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                traffic = pmc[dom_name.split(" ")[0]]["hbm_bytes_per_launch"]
+            # PMC counters cannot be collected inside this process: `traffic` is the per-launch HBM byte count of the
+            # dominant kernel from the last committed rocprofv3 --pmc passes over the same workload; the file records the
+            # commit it was measured at.  null when no such file exists.
+            traffic, traffic_source = None, None
+            try:
+                pj = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_FILE)))
+                key = dom_name.split(" ")[0]
+                ent = next(v for k_, v in pj["kernels"].items() if k_.startswith(key))
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_source = {"file": PMC_TRAFFIC_FILE, "commit": pj.get("commit"), "method": pj.get("method")}
             except Exception:
                 pass
+            # HBM-bound kernels: algorithmic bytes / launch time (same HIP-event pass)
+            hbm = {}
+            for i, (nm, _, _, ms) in enumerate(prof):
+                nb = prog.op_bytes[i] if i < len(prog.op_bytes) else 0.0
+                if nb > 0:
+                    hk = hbm.setdefault(nm, [0, 0.0, 0.0])
+                    hk[0] += 1
+                    hk[1] += nb
+                    hk[2] += ms
+            hbm_kernels = {k_: {"launches": v[0], "ms": v[2], "gbytes": v[1] / 1e9, "GB_per_s": v[1] / (v[2] * 1e-3) / 1e9,
+                                "frac_of_peak": v[1] / (v[2] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                           for k_, v in sorted(hbm.items(), key=lambda kv: -kv[1][2])}
             ach = dom[1] / (dom[2] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom_name, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                    "traffic_source": traffic_source,
                     "launches_per_step": dom[0], "avg_launch_ms": dom[2] / dom[0],
                     "flops_per_launch_avg": dom[1] / dom[0], "share_of_step_time": dom[2] / step_ms,
                     "conv_family": {"tflops": conv_fl / (conv_ms * 1e-3) / 1e12,
@@ -344,6 +365,7 @@ def main():
                                     "launches_per_step": sum(v[0] for v in variants.values()),
                                     "flops_per_step": conv_fl, "share_of_step_time": conv_ms / step_ms},
                     "other_ops_ms": step_ms - conv_ms,
+                    "hbm_bound_kernels": {"peak_GB_per_s": PEAK_HBM_GBS, "kernels": hbm_kernels},
                     "variants": {k: {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]}
                                  for k, v in sorted(variants.items(), key=lambda kv: -kv[1][2])}}
             prog.load_latents(z_T, cond)
@@ -378,7 +400,7 @@ def main():
     model.unet.__dict__.pop("_ctsi_programs", None)
     torch.cuda.empty_cache()
 
-    volume_wall = None
+    volume_wall, vae_legs = None, None
     if not args.no_volume and world == 1:
         v_in = (torch.rand(n, 1, args.depth_in, args.hw, args.hw, generator=gen) * 2 - 1).to(dev)
         for rep in range(2):  # first pass builds/captures programs, second is the measurement
@@ -389,6 +411,20 @@ def main():
             volume_wall = time.perf_counter() - t1
         finite = finite and bool(torch.isfinite(v_out).all().item()) and tuple(v_out.shape) == (n, 1, args.depth_out,
                                                                                                  args.hw, args.hw)
+        # the two frozen-VAE legs of the volume on their own (programs are cached by the generate() calls above)
+        vae_legs = {}
+        z_lat = torch.randn(shape, generator=gen).to(dev)
+        for leg, fn, arg in (("encode", model.vae.encode, v_in), ("decode", model.vae.decode, z_lat)):
+            fn(arg)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fn(arg)
+            torch.cuda.synchronize()
+            leg_s = time.perf_counter() - t1
+            progs = [pr for k_, pr in model.vae.__dict__.get("_ctsi_programs", {}).items() if k_[0] == leg[:3]]
+            fl = progs[-1].flops if progs else 0.0
+            vae_legs[leg] = {"ms": leg_s * 1e3, "tflop": fl / 1e12, "tflops": fl / leg_s / 1e12,
+                             "frac": fl / leg_s / 1e12 / PEAK_BF16_TFLOPS}
 
     if rank == 0:
         steps_total = args.steps * world * n
@@ -409,6 +445,7 @@ def main():
             "cpu_baseline": None if (args.no_cpu or world > 1) else cpu_baseline(args.cpu_threads, args.hw // 4,
                                                                                   args.depth_out),
             "volume_wall_s": volume_wall,
+            "vae": vae_legs if (not args.no_volume and world == 1) else None,
         }
         print(json.dumps(res))
     if dist is not None:

@@ -1,0 +1,39 @@
+"""rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE (one pass, csv) ->
+profiles/<out>.json: per kernel, the share of SIMD cycles with the MFMA pipe busy and the LDS bank-conflict share.
+
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace \
+        --output-format csv -d gpurun_out/pmc_mfma -o mfma -- python3 tools/profile_ops.py --repeats 1
+    python tools/pmc_mfma.py gpurun_out/pmc_mfma/mfma_counter_collection.csv profiles/r02_pmc_mfma_busy.json <commit>
+
+GRBM_GUI_ACTIVE is summed over the 8 XCDs: mfma_busy_frac = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024 SIMDs)."""
+import csv
+import json
+import re
+import sys
+
+path, out = sys.argv[1:3]
+commit = sys.argv[3] if len(sys.argv) > 3 else None
+agg = {}
+with open(path) as f:
+    for row in csv.DictReader(f):
+        name = re.sub(r"\(.*$", "", row["Kernel_Name"]).replace("void ", "").strip()
+        a = agg.setdefault(name, {})
+        c = a.setdefault(row["Counter_Name"], [0, 0.0])
+        c[0] += 1
+        c[1] += float(row["Counter_Value"])
+res = {"commit": commit, "method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE "
+                                   "over tools/profile_ops.py --repeats 1 (eager U-Net evaluations @ latent (1,8,48,128,128))",
+       "kernels": {}}
+for name, a in agg.items():
+    if "SQ_VALU_MFMA_BUSY_CYCLES" not in a or "GRBM_GUI_ACTIVE" not in a:
+        continue
+    busy, gui = a["SQ_VALU_MFMA_BUSY_CYCLES"][1], a["GRBM_GUI_ACTIVE"][1]
+    if busy <= 0 or gui <= 0:
+        continue
+    conf = a.get("SQ_LDS_BANK_CONFLICT", [0, 0.0])[1]
+    act = a.get("SQ_LDS_IDX_ACTIVE", [0, 1.0])[1]
+    res["kernels"][name] = {"launches": a["GRBM_GUI_ACTIVE"][0], "mfma_busy_frac": busy / (gui / 8.0 * 1024.0),
+                            "lds_bank_conflict_frac": conf / act if act > 0 else None}
+json.dump(res, open(out, "w"), indent=1)
+for k, v in sorted(res["kernels"].items(), key=lambda kv: -kv[1]["mfma_busy_frac"]):
+    print(f"{k[:70]:70s} launches {v['launches']:4d}  MFMA busy {100 * v['mfma_busy_frac']:5.1f} %")

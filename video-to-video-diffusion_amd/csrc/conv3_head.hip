@@ -9,13 +9,16 @@
 // with zero rows).  What bounds it then: every A fragment (1 KB per wave read) feeds a single 16-cycle MFMA, so the LDS
 // read rate is 27 x voxels x 2*Cin bytes (5.4 GB for the U-Net head) at 256 B/clk/CU -> ~45-70 us instead of 470.
 //
-// Block = 4 waves, output tile 2 x 4 x 16 voxels (8 W-lines, 2 per wave) x 16 couts; LDS = 27 KB halo + 27 KB weights
+// Block = 4 waves, output tile 4 x 2 x 16 voxels (8 W-lines, 2 per wave) x 16 couts; LDS = 27 KB halo + 27 KB weights
 // (single-buffered: two blocks share a CU, one computes while the other waits for its DMA) + row table + column sums.
 // Output: fp32 with arbitrary strides (+ optional tanh) or bf16 NDHWC, + per-tile GroupNorm column sums on request.
 #include "conv3_halo_common.h"
 
 namespace hd3 {
-constexpr int TD = 2, TH = 4, TW = 16;
+// 4 x 2 x 16: H neighbours run at the same time on the same XCD and share their halo rows in L2; depth neighbours are
+// hundreds of blocks apart, so the depth halo is what reaches HBM: (TD + 2) / TD = 1.5x the input with TD = 4 (a 2 x 4 x 16
+// tile measured 422 MB per launch for the 201 MB input of the 48 x 128 x 128 head, profiles/r02_pmc_traffic.json).
+constexpr int TD = 4, TH = 2, TW = 16;
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
 constexpr int HV = HD * HH * HW;                 // 432 halo voxels
 constexpr int HALO_INSTR = (HV + 15) / 16;       // 27 DMA wave-instructions of 16 voxels x 64 B

@@ -885,8 +885,8 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             p->halo3 = pick;
             if (pick == 5) p->BM = 512;
         }
-        // few output channels (network heads: 128 -> 8, 128 -> 1): halo tile 2x4x16 x 16 couts, see conv3_head.hip
-        const long long padded_h = (long long)ceil_div(p->Dr, 2) * ceil_div(p->Hr, 4) * ceil_div(p->Wr, 16) * 128;
+        // few output channels (network heads: 128 -> 8, 128 -> 1): halo tile 4x2x16 x 16 couts, see conv3_head.hip
+        const long long padded_h = (long long)ceil_div(p->Dr, 4) * ceil_div(p->Hr, 2) * ceil_div(p->Wr, 16) * 128;
         if (!p->halo3 && k3 && !p->small && d.c2 == 0 && d.c1 % 32 == 0 && d.cout <= 16 && (rows * 10 >= padded_h * 7 || getenv("CTSI_CONV_FORCE_HALO3")) &&
             extent < 2.0e9 && !getenv("CTSI_CONV_NO_HEAD3")) {
             p->halo3 = 6;
@@ -903,7 +903,7 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     } else if (p->halo3 == 2) {
         p->TD = 4; p->TH = p->h32_w16 ? 4 : 2; p->TW = p->h32_w16 ? 16 : 32;
     } else if (p->halo3 == 6) {
-        p->TD = 2; p->TH = 4; p->TW = 16;
+        p->TD = 4; p->TH = 2; p->TW = 16;
     } else if (p->halo3) {
         p->TD = 4; p->TH = 4; p->TW = 16;
     } else {

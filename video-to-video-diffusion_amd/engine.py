@@ -132,6 +132,7 @@ class Program:
         self.lib = ctx.lib
         self.ops: List[Callable[[], None]] = []
         self.op_meta: List[Tuple[str, float, str]] = []
+        self.op_bytes: List[float] = []
         self.pool = _Pool(ctx.device)
         self.keep: List[object] = []       # tensors / ctypes structs that must outlive the ops
         self.plans: List[C.c_void_p] = []  # conv plan handles (destroyed with the program)
@@ -148,9 +149,11 @@ class Program:
         self._versions: Tuple[int, ...] = ()
         self.shard = None  # parallel.ShardSpec for depth-sharded programs
 
-    def _emit(self, fn: Callable[[], None], name: str = "op", flops: float = 0.0, kernel: str = ""):
+    def _emit(self, fn: Callable[[], None], name: str = "op", flops: float = 0.0, kernel: str = "", nbytes: float = 0.0):
+        """`nbytes`: algorithmic HBM bytes of an HBM-bound op (what bench.py divides by the launch time for GB/s)."""
         self.ops.append(fn)
         self.op_meta.append((name, flops, kernel))
+        self.op_bytes.append(float(nbytes))
 
     # ---- buffers -------------------------------------------------------------------------------------
     def act(self, n, c, d, h, w, halo: Optional[int] = None) -> Act:
@@ -427,7 +430,7 @@ class Program:
         def run():
             lib.gn_colsum(xp, _ptr(prog._colsum), n, c, d, h, w, None, sptr)
 
-        self._emit(run, "gn.colsum")
+        self._emit(run, "gn.colsum", nbytes=2.0 * n * c * d * h * w)
         return dict(tps=tps, cpad=x.c, nclass=1)
 
     def gn_apply(self, x: Act, slot: int, gn: nn.GroupNorm, *, silu_pre: bool, tbias=None,
@@ -462,7 +465,7 @@ class Program:
             lib.gn_apply(xp, yp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, n, c, d, h, w, d_stat,
                          groups, eps, int(silu_pre), tbp, tbias_stride, stp, rp, int(silu_post), sptr)
 
-        self._emit(run, "gn.apply")
+        self._emit(run, "gn.apply", nbytes=(2 + (residual is not None)) * 2.0 * n * c * d * h * w)
         if fresh:
             self.zero_end_halos(out)
         return out
@@ -525,7 +528,7 @@ class Program:
         def run_ds():
             lib.attn_depthsum(xp, dsp, _ptr(prog._colsum), n, c, d, h, w, sptr)
 
-        self._emit(run_ds, "attn.depthsum")
+        self._emit(run_ds, "attn.depthsum", nbytes=2.0 * n * c * d * h * w)
         slot = self.gn_finalize(x, m.norm.num_groups, dict(tps=tps, cpad=c, nclass=1))
         if self.shard is not None and x.halo:
             # one sync point: GroupNorm statistics (fp64) + the depth sum (fp32) over all ranks
@@ -584,7 +587,7 @@ class Program:
         def run_ba():
             lib.attn_broadcast_add(xep, pp, rsp2, heads, op_, n, c, d_ext, h, w, sptr)
 
-        self._emit(run_ba, "attn.broadcast_add")
+        self._emit(run_ba, "attn.broadcast_add", nbytes=4.0 * n * c * d_ext * h * w)
         self.zero_end_halos(out)
         self.release(pterm)
         if rowsum is not None:
@@ -834,7 +837,7 @@ class UNetProgram(Program):
         def run_adv():
             lib.step_advance(sp, sptr)
 
-        self._emit(run_step, "sampler.step")
+        self._emit(run_step, "sampler.step", nbytes=(4 + 4 + 4 + 2 + (4 if with_noise else 0)) * float(n * L * d * h * w))
         self._emit(run_adv, "sampler.advance")
         self.sampler_kind = (kind, with_noise)
 

@@ -201,15 +201,20 @@ int ctsi_trilinear_depth_fwd(const float* src_f32_ncdhw, void* dst_bf16_ndhwc, i
  * place and a bf16 copy is written into channels [c_off, c_off+c) of the U-Net input tensor.
  * noise (fp32 NCDHW, the layout torch.randn_like(z) has) may be NULL.
  * ctsi_step_advance increments the device-side step counter (last node of a step graph).   */
+/* nonfinite (DDIM only, may be NULL): int32 table [steps][6], row *step_ptr += {noise_pred NaN, Inf, z_0_pred NaN, Inf,
+ * z-after-update NaN, Inf} -- what the reference's per-step guards report through logger.error (inference/sampler.py:
+ * 288-292, 307-311, 331-334); the host reads it once after the loop (no sync inside the captured step).             */
 int ctsi_ddim_step(float* z, const float* eps, const float* noise_ncdhw, void* zin_bf16,
                    int c_total, int c_off, const float* coef, const int* step_ptr, int n, int c,
-                   int d, int h, int w, void* stream);
+                   int d, int h, int w, int* nonfinite, void* stream);
 int ctsi_ddpm_step(float* z, const float* eps, const float* noise_ncdhw, void* zin_bf16,
                    int c_total, int c_off, const float* coef, const int* step_ptr, int n, int c,
                    int d, int h, int w, void* stream);
 int ctsi_step_advance(int* step_ptr, void* stream);
 /* x <- nan_to_num(x, nan=0, posinf=1, neginf=-1) on a flat fp32 buffer (model.py:262-341) */
 int ctsi_nan_to_num_f32(float* x, long long count, void* stream);
+/* counts[0] += #NaN, counts[1] += #Inf of x; sanitize != 0 also applies nan_to_num (sampler.py:268-275 checkpoints) */
+int ctsi_count_nonfinite_f32(float* x, long long count, int sanitize, int* counts, void* stream);
 
 /* ---- training path (models/diffusion.py:81-247, models/model.py:158-228; backward = what autograd derives) ---- */
 /* Weight gradient of Conv3d / ConvTranspose3d:  dw[cr*stride_r + cg*stride_g + t*stride_t] =

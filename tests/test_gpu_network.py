@@ -116,10 +116,73 @@ def test_ddim_trajectory_and_psnr_criterion(golden, pkg):
         e_hip, e_bf16 = rel_l2(z.cpu(), ref[-1]), rel_l2(zb, ref[-1])
         print(f"eta={eta} per-step rel-L2 {['%.3g' % e for e in errs]}  final hip {e_hip:.3g} vs autocast {e_bf16:.3g}")
         # step 0 divides by ~1e-4 and clamps to +-10: elements whose numerator is near zero flip sign under
-        # any bf16 perturbation, so the yardstick is the reference's own bf16-autocast trajectory
-        assert e_hip < 1.25 * e_bf16 + 1e-2
+        # any bf16 perturbation, so the yardstick is the reference's own bf16-autocast trajectory.  ONE criterion, the
+        # stated one: PSNR(hip) >= PSNR(autocast) - 0.1 dB, i.e. rmse_hip <= 1.0116 * rmse_autocast on the final latent
         psnr_hip, psnr_bf = R.psnr(z.cpu(), ref[-1], 20.0), R.psnr(zb, ref[-1], 20.0)
         assert psnr_hip >= psnr_bf - 0.1, (psnr_hip, psnr_bf)
+
+
+def test_nonfinite_values_are_sanitised_and_logged(pkg, caplog):
+    """The reference's NaN/Inf checkpoints (inference/sampler.py:268-275, 288-292): values are sanitised on device and
+    what the reference would have logged is logged once per sample(), from device-side counters."""
+    import logging
+    model, sd, cfg = tiny_model_sd(pkg)
+    model.to(DEV)
+    shape = (1, 8, 4, 8, 8)
+    cond = formula_input(shape, 15)
+    cond[0, 1, 2, 3, 4] = float("inf")
+
+    def nf(i, s_):
+        z = formula_noise(i, s_)
+        if i == -1:
+            z[0, 0, 0, 0, :3] = float("nan")
+        return z
+
+    with caplog.at_level(logging.ERROR):
+        z = pkg.DDIMSampler(model.diffusion, model.unet).sample(shape, cond.to(DEV), 3, DEV, progress=False, noise_fn=nf)
+    assert torch.isfinite(z).all()
+    text = caplog.text
+    assert "NaN/Inf in initial noise z! NaN: 3, Inf: 0" in text
+    assert "NaN/Inf in conditioning! NaN: 0, Inf: 1" in text
+    caplog.clear()
+    with caplog.at_level(logging.ERROR):
+        pkg.DDIMSampler(model.diffusion, model.unet).sample(shape, formula_input(shape, 15).to(DEV), 3, DEV,
+                                                            progress=False, noise_fn=_noise_fn)
+    assert "NaN/Inf" not in caplog.text          # healthy run: silent
+
+
+def test_sampler_over_a_generic_callable(golden, pkg):
+    """The reference's samplers take any model(z, t, c) callable (inference/sampler.py:211-219).  A plain torch function
+    goes through the engine's update kernels step by step; wrapping the engine's own U-Net that way must reproduce the
+    captured-graph path, and a non-callable is refused."""
+    model, sd, cfg = tiny_model_sd(pkg)
+    model.to(DEV)
+    shape = (1, 8, 4, 8, 8)
+    cond = formula_input(shape, 15).to(DEV)
+    unet = model.unet
+    wrapped = lambda z, t, c: unet(z, t, c)        # not a UNet3D instance: the generic path
+    for cls, kw in ((pkg.DDIMSampler, dict(num_inference_steps=5, eta=0.3)), (pkg.DDPMSampler, dict(num_steps=5))):
+        a_t, b_t = [], []
+        if cls is pkg.DDIMSampler:
+            a = cls(model.diffusion, unet).sample(shape, cond, 5, DEV, eta=0.3, progress=False, noise_fn=_noise_fn,
+                                                  trajectory=a_t)
+            b = cls(model.diffusion, wrapped).sample(shape, cond, 5, DEV, eta=0.3, progress=False, noise_fn=_noise_fn,
+                                                     trajectory=b_t)
+        else:
+            a = cls(model.diffusion, unet).sample(shape, cond, DEV, progress=False, noise_fn=_noise_fn, num_steps=5,
+                                                  trajectory=a_t)
+            b = cls(model.diffusion, wrapped).sample(shape, cond, DEV, progress=False, noise_fn=_noise_fn, num_steps=5,
+                                                     trajectory=b_t)
+        assert len(a_t) == len(b_t) and tuple(b.shape) == shape
+        assert rel_l2(b.cpu(), a.cpu()) < 1e-5, cls.__name__     # same kernels; only the bf16 input copy path differs
+    # a pure-torch epsilon model (no engine inside) against the oracle's sampler on the same callable
+    toy = lambda z, t, c: 0.1 * z + 0.05 * c
+    got = pkg.DDIMSampler(model.diffusion, toy).sample(shape, cond, 10, DEV, progress=False, noise_fn=_noise_fn)
+    bufs = R.diffusion_buffers("cosine", 1000)
+    ref = R.ddim_sample(lambda z, t, c: 0.1 * z + 0.05 * c, bufs, shape, cond.cpu(), 10, noise_fn=_noise_fn)
+    assert rel_l2(got.cpu(), ref) < 1e-5
+    with pytest.raises(pkg.CtsiError, match="callable"):
+        pkg.DDIMSampler(model.diffusion, object()).sample(shape, cond, 3, DEV, progress=False)
 
 
 def test_ddpm_first_steps(golden, pkg):
@@ -149,7 +212,13 @@ def test_generate_end_to_end(golden, pkg):
     from inference.generate import generate_batch
     outb = generate_batch(model, v_in, 'ddim', 5, DEV, noise_fn=_noise_fn)
     assert tuple(outb.shape) == (1, 1, 2, 32, 32)
-    assert R.psnr(outb.cpu(), torch.tensor(golden["generate_batch.tiny.out"]), 2.0) >= 25.0
+    # same relative criterion as generate(): generate_batch = encode -> sample at the input depth -> decode
+    # (inference/generate.py:118-155), which is the oracle's generate() with target_depth=None
+    refb = torch.tensor(golden["generate_batch.tiny.out"])
+    outb_bf = _bf16_autocast_reference(lambda: R.generate(sd, cfg, v_in, "ddim", 5, None, noise_fn=_noise_fn))
+    pb_hip, pb_bf = R.psnr(outb.cpu(), refb, 2.0), R.psnr(outb_bf, refb, 2.0)
+    print(f"generate_batch PSNR vs reference fp32: hip {pb_hip:.2f} dB, reference-under-bf16-autocast {pb_bf:.2f} dB")
+    assert pb_hip >= pb_bf - 0.1
     # default RNG path (no injected noise): runs, finite, deterministic under a fixed seed
     torch.manual_seed(3)
     a = model.generate(v_in.to(DEV), 'ddim', num_inference_steps=3, target_depth=4)
@@ -215,19 +284,23 @@ def test_sample_with_stitching(golden, pkg):
     with pytest.raises(pkg.CtsiError, match="must equal the thick patch"):
         sampler.sample_with_stitching(v_full.to(DEV), model.vae, 3, patch_size=(4, 16, 16),
                                       target_patch_size=(12, 8, 16), stride=(2, 8, 8), device=DEV, progress=False)
-    # depth_ratio 3 (the reference raises a shape error here; intended behaviour = per-window depth upsample of
-    # the conditioning latent, checked against the oracle's restatement of that intent)
-    nf = lambda i, s_: formula_noise(-1, s_)
-    out3 = S._stitched(sampler, v_full, model.vae, (4, 16, 16), (12, 16, 16), (2, 8, 8), DEV, False,
-                       lambda shp, cond: sampler.sample(shp, cond, 3, DEV, progress=False, noise_fn=nf))
-    ref3 = R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8), noise_fn=nf, target_d=12)
-    ref3_bf = _bf16_autocast_reference(lambda: R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8),
-                                                               noise_fn=nf, target_d=12))
-    p3, p3_bf = R.psnr(out3.cpu(), ref3, 2.0), R.psnr(ref3_bf, ref3, 2.0)
-    print(f"stitching depth_ratio 3 PSNR vs oracle fp32: hip {p3:.2f} dB, oracle under bf16 autocast {p3_bf:.2f} dB")
-    # two different bf16 rounding realisations of a chaotic 3-step, random-weight pipeline: their PSNRs scatter
-    # by a few tenths of a dB around each other (measured 27.79 vs 27.97), hence 0.5 dB here, not 0.1
-    assert tuple(out3.shape) == (1, 1, 18, 24, 24) and p3 >= p3_bf - 0.5
+    # depth_ratio 3 (the reference raises a shape error here; intended behaviour = per-window depth upsample of the
+    # conditioning latent, checked against the oracle's restatement of that intent).  Two bf16 realisations of a chaotic
+    # 3-step random-weight pipeline scatter by a few tenths of a dB around each other on ONE noise draw, so the criterion
+    # is stated over 8 independent noise seeds: mean(PSNR_hip - PSNR_autocast) >= -0.1 dB.
+    deltas = []
+    for seed in range(8):
+        nf = lambda i, s_, k=seed: formula_noise(100 + 7 * k, s_)
+        out3 = S._stitched(sampler, v_full, model.vae, (4, 16, 16), (12, 16, 16), (2, 8, 8), DEV, False,
+                           lambda shp, cond: sampler.sample(shp, cond, 3, DEV, progress=False, noise_fn=nf))
+        ref3 = R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8), noise_fn=nf, target_d=12)
+        ref3_bf = _bf16_autocast_reference(lambda: R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8),
+                                                                   noise_fn=nf, target_d=12))
+        assert tuple(out3.shape) == (1, 1, 18, 24, 24)
+        deltas.append(R.psnr(out3.cpu(), ref3, 2.0) - R.psnr(ref3_bf, ref3, 2.0))
+    print("stitching depth_ratio 3, PSNR(hip) - PSNR(oracle under bf16 autocast) over 8 seeds:",
+          ["%.2f" % v for v in deltas], "mean %.3f dB" % (sum(deltas) / len(deltas)))
+    assert sum(deltas) / len(deltas) >= -0.1
     # the two blend kernels alone, bit-for-bit against torch
     E = importlib.import_module("video-to-video-diffusion_amd.engine")
     ctx = E.Ctx.get(torch.device(DEV))

@@ -222,6 +222,17 @@ def test_conv_linearity_and_zero_padding_property(G):
     assert torch.equal(y, bf16_round(ref))
 
 
+def test_groupnorm_statistics_are_bit_stable(G):
+    """ctsi_gn_finalize has no atomics: one block per (sample, group), fixed-order reduce -> the fp64 (sum, sumsq) are
+    bit-identical from run to run, also with thousands of tile partials."""
+    x = bf16_round(formula_input((2, 64, 8, 32, 64), 41))
+    wt = bf16_round(_w((128, 64, 3, 3, 3), 42))
+    b = formula_input((128,), 43) * 0.1
+    runs = [G.run_conv(x, None, wt, b, want_stats=True, groups=32)[1] for _ in range(4)]
+    for s_ in runs[1:]:
+        assert torch.equal(s_, runs[0])
+
+
 def test_groupnorm_apply_variants(G):
     E, ctx = G.E, G.ctx()
     n, c, d, h, w = 2, 64, 3, 5, 7
@@ -348,10 +359,14 @@ def test_sampler_update_kernels(G, pkg):
                 sp = torch.tensor([step], dtype=torch.int32, device=dev)
                 cf = coef.to(dev).contiguous()
                 nz = noise.to(dev).contiguous()
-                fn = c.lib.ddim_step if kind == "ddim" else c.lib.ddpm_step
                 use_noise = kind == "ddpm" or eta > 0
-                fn(G._ptr(zn), G._ptr(en), G._ptr(nz) if use_noise else None, G._ptr(zin), 2 * L, 0, G._ptr(cf),
-                   G._ptr(sp), n, L, d, h, w, c.sptr)
+                nf = torch.zeros(len(coef), 6, dtype=torch.int32, device=dev)
+                if kind == "ddim":
+                    c.lib.ddim_step(G._ptr(zn), G._ptr(en), G._ptr(nz) if use_noise else None, G._ptr(zin), 2 * L, 0,
+                                    G._ptr(cf), G._ptr(sp), n, L, d, h, w, G._ptr(nf), c.sptr)
+                else:
+                    c.lib.ddpm_step(G._ptr(zn), G._ptr(en), G._ptr(nz), G._ptr(zin), 2 * L, 0, G._ptr(cf), G._ptr(sp), n,
+                                    L, d, h, w, c.sptr)
                 out = torch.empty(shape, device=dev)
                 c.lib.ndhwc_f32_to_ncdhw_f32(G._ptr(zn), G._ptr(out), n, L, d, h, w, c.sptr)
             torch.cuda.synchronize()
@@ -365,6 +380,9 @@ def test_sampler_update_kernels(G, pkg):
                 z0 = torch.clamp((z - r[0] * e) / r[1], -1, 1)
                 ref = r[2] * z0 + r[3] * z + r[4] * noise
             assert rel_l2(out.cpu(), ref) < 1e-6, (kind, eta, step)
+            if kind == "ddim":   # the device-side tally of what the reference's guards would log: one NaN and one Inf in
+                cnt = nf.cpu()   # noise_pred at this step's row, nothing downstream (both were sanitised before use)
+                assert cnt[step].tolist() == [1, 1, 0, 0, 0, 0] and int(cnt.sum()) == 2
             zb = zin.float().reshape(n, d, h, w, 2 * L)[..., :L].permute(0, 4, 1, 2, 3).cpu()
             assert rel_l2(zb, bf16_round(out.cpu())) < 1e-6
             assert float(zin.float().reshape(n, d, h, w, 2 * L)[..., L:].abs().max()) == 0.0

@@ -254,13 +254,24 @@ extern "C" int ctsi_time_embed_train_fwd(const int* t_rows, int rows, int dim, i
 //  DDIM: [0]=sqrt(1-a_t+1e-8) [1]=sqrt(a_t+1e-8)+1e-8 [2]=sqrt(a_prev+1e-8) [3]=sqrt(1-a_prev+1e-8) [4]=sigma_t
 //  DDPM: [0]=sqrt(1-abar_t)   [1]=sqrt(abar_t)        [2]=post_mean_coef1   [3]=post_mean_coef2     [4]=(t!=0)*exp(0.5*logvar)
 // z, eps: fp32 NDHWC.  noise: fp32 NCDHW (the layout torch.randn_like(z) has in the reference) or NULL.
+// nonfinite: optional [steps][6] int32 table, row = *step_ptr: how many elements the reference's guards would have
+// reported at this step -- {noise_pred NaN, Inf, z_0_pred NaN, Inf, z after update NaN, Inf} (inference/sampler.py:
+// 288-292, 307-311, 331-334).  The guards themselves (nan_to_num) are applied unconditionally; the host reads the table
+// once after the loop and logs what the reference logs, so the captured step never synchronises.
+__device__ __forceinline__ void count_nonfinite(float v, int& n_nan, int& n_inf) {
+    n_nan += (v != v) ? 1 : 0;
+    n_inf += (v == __builtin_inff() || v == -__builtin_inff()) ? 1 : 0;
+}
+
 template <bool DDPM>
 __global__ void __launch_bounds__(256)
 sampler_step_kernel(float* __restrict__ z, const float* __restrict__ eps, const float* __restrict__ noise,
                     bf16_t* __restrict__ zin, int c_total, int c_off, const float* __restrict__ coef,
-                    const int* __restrict__ step_ptr, int c, long long vox, long long total) {
-    const float* cf = coef + (long long)(step_ptr ? *step_ptr : 0) * 8;
+                    const int* __restrict__ step_ptr, int c, long long vox, long long total, int* __restrict__ nonfinite) {
+    const int step = step_ptr ? *step_ptr : 0;
+    const float* cf = coef + (long long)step * 8;
     const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4];
+    int cnt[6] = {0, 0, 0, 0, 0, 0};
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int ch = (int)(e % c);
         const long long nv = e / c;  // n*vox + v
@@ -276,8 +287,10 @@ sampler_step_kernel(float* __restrict__ z, const float* __restrict__ eps, const 
                 zn += c4 * noise[(nb * c + ch) * vox + v];
             }
         } else {
+            count_nonfinite(ep, cnt[0], cnt[1]);
             ep = nan_to_num_f(ep);
             float z0 = (zt - c0 * ep) / c1;
+            count_nonfinite(z0, cnt[2], cnt[3]);
             z0 = nan_to_num_f(z0);
             z0 = fminf(fmaxf(z0, -10.0f), 10.0f);
             zn = c2 * z0 + c3 * ep;
@@ -285,36 +298,46 @@ sampler_step_kernel(float* __restrict__ z, const float* __restrict__ eps, const 
                 const long long nb = nv / vox, v = nv - nb * vox;
                 zn += c4 * noise[(nb * c + ch) * vox + v];
             }
+            count_nonfinite(zn, cnt[4], cnt[5]);
             zn = nan_to_num_f(zn);
         }
         z[e] = zn;
         if (zin) zin[nv * c_total + c_off + ch] = f32_to_bf16(zn);
     }
+    if (!DDPM && nonfinite != nullptr) {
+        const int any = cnt[0] | cnt[1] | cnt[2] | cnt[3] | cnt[4] | cnt[5];
+        if (__any(any != 0)) {   // never taken on healthy runs: no atomics, no divergence cost
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (cnt[k]) atomicAdd(&nonfinite[step * 6 + k], cnt[k]);
+        }
+    }
 }
 
 template <bool DDPM>
 static int sampler_step(float* z, const float* eps, const float* noise, void* zin, int c_total, int c_off,
-                        const float* coef, const int* step_ptr, int n, int c, int d, int h, int w, void* stream) {
+                        const float* coef, const int* step_ptr, int n, int c, int d, int h, int w, int* nonfinite,
+                        void* stream) {
     CTSI_CHECK_ARG(z && eps && coef, "sampler step: null argument");
     CTSI_CHECK_ARG(!zin || (c_off >= 0 && c_off + c <= c_total), "sampler step: bad channel slice");
     const long long vox = (long long)d * h * w, total = vox * n * c;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((sampler_step_kernel<DDPM>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z,
-                       eps, noise, (bf16_t*)zin, c_total, c_off, coef, step_ptr, c, vox, total);
+                       eps, noise, (bf16_t*)zin, c_total, c_off, coef, step_ptr, c, vox, total, nonfinite);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }
 
 extern "C" int ctsi_ddim_step(float* z, const float* eps, const float* noise, void* zin, int c_total, int c_off,
                               const float* coef, const int* step_ptr, int n, int c, int d, int h, int w,
-                              void* stream) {
-    return sampler_step<false>(z, eps, noise, zin, c_total, c_off, coef, step_ptr, n, c, d, h, w, stream);
+                              int* nonfinite, void* stream) {
+    return sampler_step<false>(z, eps, noise, zin, c_total, c_off, coef, step_ptr, n, c, d, h, w, nonfinite, stream);
 }
 extern "C" int ctsi_ddpm_step(float* z, const float* eps, const float* noise, void* zin, int c_total, int c_off,
                               const float* coef, const int* step_ptr, int n, int c, int d, int h, int w,
                               void* stream) {
-    return sampler_step<true>(z, eps, noise, zin, c_total, c_off, coef, step_ptr, n, c, d, h, w, stream);
+    return sampler_step<true>(z, eps, noise, zin, c_total, c_off, coef, step_ptr, n, c, d, h, w, nullptr, stream);
 }
 
 __global__ void step_advance_kernel(int* step_ptr) {
@@ -327,16 +350,37 @@ extern "C" int ctsi_step_advance(int* step_ptr, void* stream) {
     return CTSI_OK;
 }
 
-__global__ void __launch_bounds__(256) nan_to_num_kernel(float* x, long long count) {
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256)
-        x[e] = nan_to_num_f(x[e]);
+__global__ void __launch_bounds__(256) nan_to_num_kernel(float* x, long long count, int sanitize, int* counts) {
+    int n_nan = 0, n_inf = 0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256) {
+        const float v = x[e];
+        count_nonfinite(v, n_nan, n_inf);
+        if (sanitize) x[e] = nan_to_num_f(v);
+    }
+    if (counts != nullptr && __any((n_nan | n_inf) != 0)) {
+        if (n_nan) atomicAdd(&counts[0], n_nan);
+        if (n_inf) atomicAdd(&counts[1], n_inf);
+    }
 }
 extern "C" int ctsi_nan_to_num_f32(float* x, long long count, void* stream) {
     CTSI_CHECK_ARG(x && count >= 0, "ctsi_nan_to_num_f32: bad arguments");
     if (count == 0) return CTSI_OK;
     long long blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(nan_to_num_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, count);
+    hipLaunchKernelGGL(nan_to_num_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, count, 1,
+                       (int*)nullptr);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+// counts[0] += #NaN, counts[1] += #Inf of x (the reference's `torch.isnan(z).sum()` / `torch.isinf(z).sum()` of its
+// NaN/Inf checkpoints, inference/sampler.py:268-275) without a host round trip; sanitize != 0 also applies nan_to_num.
+extern "C" int ctsi_count_nonfinite_f32(float* x, long long count, int sanitize, int* counts, void* stream) {
+    CTSI_CHECK_ARG(x && counts && count >= 0, "ctsi_count_nonfinite_f32: bad arguments");
+    if (count == 0) return CTSI_OK;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nan_to_num_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, count, sanitize,
+                       counts);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

@@ -824,14 +824,20 @@ class UNetProgram(Program):
         n, L, d, h, w = self.n, self.L, self.d, self.h, self.w
         if with_noise and self.noise is None:
             self.noise = self.persistent((n, L, d, h, w), torch.float32, zero=True)
-        fn = lib.ddim_step if kind == "ddim" else lib.ddpm_step
         zp, ep, xp, cp, sp = _ptr(self.z), _ptr(self.eps), self.xin.ip, _ptr(self.coef), _ptr(self.step_ptr)
         npz = _ptr(self.noise if with_noise else None)
+        # what the reference's NaN/Inf checkpoints would report: rows 0..max_rows-1 = per step {noise_pred, z_0_pred, z}
+        # x {NaN, Inf}; the two extra rows = initial noise and conditioning (sampler.py:268-275).  Read once per sample().
+        self.nonfinite = self.persistent((self.max_rows + 2, 6), torch.int32, zero=True)
+        nfp = _ptr(self.nonfinite)
 
         xin = self.xin
 
         def run_step():
-            fn(zp, ep, npz, xp, 2 * L, 0, cp, sp, n, L, d, h, w, sptr)
+            if kind == "ddim":
+                lib.ddim_step(zp, ep, npz, xp, 2 * L, 0, cp, sp, n, L, d, h, w, nfp, sptr)
+            else:
+                lib.ddpm_step(zp, ep, npz, xp, 2 * L, 0, cp, sp, n, L, d, h, w, sptr)
             xin.dirty = True
 
         def run_adv():

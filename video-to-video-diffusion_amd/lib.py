@@ -98,10 +98,11 @@ SIGNATURES = {
     "ctsi_attn_softmax_rowsum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_time_embed_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp], True),
     "ctsi_trilinear_depth_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp], True),
-    "ctsi_ddim_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp], True),
+    "ctsi_ddim_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], True),
     "ctsi_ddpm_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_step_advance": (_i, [_vp, _vp], True),
     "ctsi_nan_to_num_f32": (_i, [_vp, _ll, _vp], True),
+    "ctsi_count_nonfinite_f32": (_i, [_vp, _ll, _i, _vp, _vp], True),
     "ctsi_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)], False),
     "ctsi_wgrad_flops": (C.c_double, [C.POINTER(WgradDesc)], False),
     "ctsi_wgrad": (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _vp, _ll, _ll, _ll, _f, _vp], True),

@@ -26,11 +26,87 @@ except Exception:  # pragma: no cover
     tqdm = None
 
 
-def _unet_of(model):
-    if type(model).__name__ != "UNet3D" or not hasattr(model, "program"):
-        raise CtsiError("the HIP samplers drive a video-to-video-diffusion_amd UNet3D; got "
-                        f"{type(model).__name__} (wrap-free engine, no generic callable path)")
-    return model
+def _is_engine_unet(model) -> bool:
+    return type(model).__name__ == "UNet3D" and hasattr(model, "program")
+
+
+def _log_nonfinite(kind: str, table: torch.Tensor, steps: int, max_rows: int):
+    """What the reference's five NaN/Inf checkpoints log (inference/sampler.py:268-275, 288-292, 307-311, 331-334), from
+    the device-side counters the update kernel keeps: one host read after the loop instead of five syncs per step."""
+    if kind != "ddim":
+        return            # the reference's DDPM loop (models/diffusion.py:340-367) has no such checkpoints
+    t = table.cpu()
+    if not bool(t.any()):
+        return
+    init, cond = t[max_rows], t[max_rows + 1]
+    if int(init[0]) or int(init[1]):
+        logger.error(f"NaN/Inf in initial noise z! NaN: {int(init[0])}, Inf: {int(init[1])}")
+    if int(cond[0]) or int(cond[1]):
+        logger.error(f"NaN/Inf in conditioning! NaN: {int(cond[0])}, Inf: {int(cond[1])}")
+    for i in range(steps):
+        r = [int(v) for v in t[i]]
+        if r[0] or r[1]:
+            logger.error(f"[Step {i}/{steps}] NaN/Inf in noise_pred! NaN: {r[0]}, Inf: {r[1]}")
+        if r[2] or r[3]:
+            logger.error(f"[Step {i}/{steps}] NaN/Inf in z_0_pred! NaN: {r[2]}, Inf: {r[3]}")
+        if r[4] or r[5]:
+            logger.error(f"[Step {i}/{steps}] NaN/Inf in z after update! NaN: {r[4]}, Inf: {r[5]}")
+
+
+def _run_sampler_generic(diffusion, model, shape, conditioning, ctx, z0, *, kind, t_desc, eta, noise_fn, progress,
+                         trajectory):
+    """Reverse loop over an ARBITRARY `model(z, t, c) -> eps` callable (the reference's samplers accept any,
+    inference/sampler.py:211-219): the network evaluation is the caller's (any torch code on the ROCm device), the
+    x_{t-1} update with its guards is the engine's ctsi_ddim_step / ctsi_ddpm_step.  Not captured: the callable is
+    opaque.  The engine's own UNet3D takes the hipGraph path in run_sampler instead."""
+    import ctypes as C
+    lib, sptr = ctx.lib, ctx.sptr
+    n, L, d, h, w = [int(v) for v in shape]
+    steps = len(t_desc)
+    with_noise = (kind == "ddpm") or eta > 0
+    dev = ctx.device
+    coef = (ddim_coef_rows(diffusion.alphas_cumprod, t_desc, eta) if kind == "ddim"
+            else diffusion.ddpm_coef_rows(t_desc)).to(dev, torch.float32).contiguous()
+    z_nd = torch.empty((n, d, h, w, L), dtype=torch.float32, device=dev)
+    eps_nd = torch.empty_like(z_nd)
+    step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+    nonfinite = torch.zeros((steps + 2, 6), dtype=torch.int32, device=dev)
+    cond = conditioning.to(dev)
+    z = z0.to(dev, torch.float32).contiguous()
+    with ctx.scope():
+        lib.count_nonfinite_f32(_ptr(z), z.numel(), 1, C.c_void_p(nonfinite.data_ptr() + steps * 24), sptr)
+        cf = cond.float().contiguous()
+        lib.count_nonfinite_f32(_ptr(cf), cf.numel(), 0, C.c_void_p(nonfinite.data_ptr() + (steps + 1) * 24), sptr)
+    it = range(steps)
+    if progress and tqdm is not None:
+        it = tqdm(it, desc=f"{kind.upper()} Sampling", total=steps)
+    for i in it:
+        t = torch.full((n,), int(t_desc[i]), device=dev, dtype=torch.long)
+        eps = model(z, t, cond)
+        if not (torch.is_tensor(eps) and tuple(eps.shape) == tuple(shape) and eps.is_cuda):
+            raise CtsiError("the model callable must return a ROCm tensor of the latent's shape "
+                            f"{tuple(shape)}, got {type(eps).__name__} {tuple(getattr(eps, 'shape', ()))}")
+        eps = eps.detach().to(torch.float32).contiguous()
+        noise = None
+        if with_noise:
+            noise = (noise_fn(i, tuple(shape)) if noise_fn is not None else torch.randn(tuple(shape), device=dev))
+            noise = noise.to(dev, torch.float32).contiguous()
+        with ctx.scope():
+            lib.ncdhw_f32_to_ndhwc_f32(_ptr(z), _ptr(z_nd), n, L, d, h, w, sptr)
+            lib.ncdhw_f32_to_ndhwc_f32(_ptr(eps), _ptr(eps_nd), n, L, d, h, w, sptr)
+            if kind == "ddim":
+                lib.ddim_step(_ptr(z_nd), _ptr(eps_nd), _ptr(noise), None, 0, 0, _ptr(coef), _ptr(step_ptr), n, L, d, h, w,
+                              _ptr(nonfinite), sptr)
+            else:
+                lib.ddpm_step(_ptr(z_nd), _ptr(eps_nd), _ptr(noise), None, 0, 0, _ptr(coef), _ptr(step_ptr), n, L, d, h, w,
+                              sptr)
+            lib.step_advance(_ptr(step_ptr), sptr)
+            z = torch.empty((n, L, d, h, w), dtype=torch.float32, device=dev)
+            lib.ndhwc_f32_to_ncdhw_f32(_ptr(z_nd), _ptr(z), n, L, d, h, w, sptr)
+        if trajectory is not None:
+            trajectory.append(z.clone())
+    _log_nonfinite(kind, nonfinite, steps, steps)
+    return z
 
 
 def ddim_coef_rows(alphas_cumprod: torch.Tensor, timesteps: Sequence[int], eta: float) -> torch.Tensor:
@@ -107,7 +183,9 @@ def run_sampler(diffusion, model, shape, conditioning, device, *, kind: str, t_d
                 progress: bool, eta: float = 0.0, noise_fn=None, z_init: Optional[torch.Tensor] = None,
                 trajectory: Optional[list] = None):
     """Shared reverse loop.  kind: 'ddim' | 'ddpm'; t_desc: descending timestep list."""
-    unet = _unet_of(model)
+    if not _is_engine_unet(model) and not callable(model):
+        raise CtsiError(f"the samplers need a model(z, t, c) callable; got {type(model).__name__}")
+    unet = model
     device = torch.device(device)
     ctx = Ctx.get(device if device.type == "cuda" else conditioning.device)
     n, L, d, h, w = [int(v) for v in shape]
@@ -121,6 +199,9 @@ def run_sampler(diffusion, model, shape, conditioning, device, *, kind: str, t_d
         z0 = noise_fn(-1, tuple(shape)).to(ctx.device)
     else:
         z0 = torch.randn(tuple(shape), device=ctx.device)
+    if not _is_engine_unet(model):
+        return _run_sampler_generic(diffusion, model, shape, conditioning, ctx, z0, kind=kind, t_desc=t_desc, eta=eta,
+                                    noise_fn=noise_fn, progress=progress, trajectory=trajectory)
     comm = getattr(unet, "depth_shard_comm", None)
     if comm is not None and comm.world > 1:
         return run_sampler_sharded(diffusion, unet, shape, conditioning, ctx, z0, kind=kind, t_desc=t_desc, eta=eta,
@@ -136,7 +217,15 @@ def run_sampler(diffusion, model, shape, conditioning, device, *, kind: str, t_d
 
         prog: UNetProgram = cached_program(unet, key, build)
         prog.load_latents(z0, conditioning)
-        nan_to_num_(ctx, prog.z)  # sampler.py:268-271 (identity on finite noise)
+        import ctypes as C
+        prog.nonfinite.zero_()
+        nf_tail = prog.nonfinite.data_ptr() + prog.max_rows * 24
+        # sampler.py:268-275: checkpoint 1 sanitises the initial noise (identity on finite values), checkpoint 2 only
+        # reports on the conditioning; both are counted on device and logged after the loop
+        ctx.lib.count_nonfinite_f32(_ptr(prog.z), prog.z.numel(), 1, C.c_void_p(nf_tail), ctx.sptr)
+        cnd = conditioning.detach().to(ctx.device, torch.float32).contiguous()
+        ctx.lib.count_nonfinite_f32(_ptr(cnd), cnd.numel(), 0, C.c_void_p(nf_tail + 24), ctx.sptr)
+        cnd.record_stream(ctx.stream)
         if kind == "ddim":
             coef = ddim_coef_rows(diffusion.alphas_cumprod, t_desc, eta)
         else:
@@ -159,7 +248,9 @@ def run_sampler(diffusion, model, shape, conditioning, device, *, kind: str, t_d
             prog.launch()
             if trajectory is not None:
                 trajectory.append(prog.z_ncdhw())
-        return prog.z_ncdhw()
+        out = prog.z_ncdhw()
+        _log_nonfinite(kind, prog.nonfinite, steps, prog.max_rows)
+        return out
 
 
 class DDPMSampler:

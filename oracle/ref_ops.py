@@ -391,9 +391,9 @@ def ddim_stitched(sd: SD, cfg: dict, v_full, n_steps: int, patch, stride, noise_
     pd, ph, pw = patch
     td = pd if target_d is None else int(target_d)
     ratio = td / pd
-    acc = torch.zeros(b, c, int(dt * ratio), hf, wf)
+    acc = torch.zeros(b, c, int(dt * ratio), hf, wf, device=v_full.device)
     wmap = torch.zeros_like(acc)
-    win = gaussian_window(td, ph, pw).view(1, 1, td, ph, pw)
+    win = gaussian_window(td, ph, pw).view(1, 1, td, ph, pw).to(v_full.device)
     model = lambda z, t, cnd: unet_forward(sd, cfg, z, t, cnd, "unet.")
     bufs = {k[len("diffusion."):]: v for k, v in sd.items() if k.startswith("diffusion.")}
     sf = cfg["scaling_factor"]

@@ -289,15 +289,17 @@ def test_sample_with_stitching(golden, pkg):
     # 3-step random-weight pipeline scatter by a few tenths of a dB around each other on ONE noise draw, so the criterion
     # is stated over 8 independent noise seeds: mean(PSNR_hip - PSNR_autocast) >= -0.1 dB.
     deltas = []
+    sd_dev = {k: v.to(DEV) for k, v in sd.items()}       # the oracle on this device: fp32, and under bf16 autocast (the
+    v_dev = v_full.to(DEV)                               # reference's own AMP path) -- 16 CPU runs would take minutes
     for seed in range(8):
-        nf = lambda i, s_, k=seed: formula_noise(100 + 7 * k, s_)
+        nf = lambda i, s_, k=seed: formula_noise(100 + 7 * k, s_).to(DEV)
         out3 = S._stitched(sampler, v_full, model.vae, (4, 16, 16), (12, 16, 16), (2, 8, 8), DEV, False,
                            lambda shp, cond: sampler.sample(shp, cond, 3, DEV, progress=False, noise_fn=nf))
-        ref3 = R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8), noise_fn=nf, target_d=12)
-        ref3_bf = _bf16_autocast_reference(lambda: R.ddim_stitched(sd, cfg, v_full, 3, (4, 16, 16), (2, 8, 8),
-                                                                   noise_fn=nf, target_d=12))
+        ref3 = R.ddim_stitched(sd_dev, cfg, v_dev, 3, (4, 16, 16), (2, 8, 8), noise_fn=nf, target_d=12)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ref3_bf = R.ddim_stitched(sd_dev, cfg, v_dev, 3, (4, 16, 16), (2, 8, 8), noise_fn=nf, target_d=12).float()
         assert tuple(out3.shape) == (1, 1, 18, 24, 24)
-        deltas.append(R.psnr(out3.cpu(), ref3, 2.0) - R.psnr(ref3_bf, ref3, 2.0))
+        deltas.append(R.psnr(out3, ref3, 2.0) - R.psnr(ref3_bf, ref3, 2.0))
     print("stitching depth_ratio 3, PSNR(hip) - PSNR(oracle under bf16 autocast) over 8 seeds:",
           ["%.2f" % v for v in deltas], "mean %.3f dB" % (sum(deltas) / len(deltas)))
     assert sum(deltas) / len(deltas) >= -0.1

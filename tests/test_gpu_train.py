@@ -170,6 +170,50 @@ def test_stale_tape_is_refused_and_weight_writes_are_seen(pkg):
     assert abs(float(model(v_in, v_gt, t=t, noise=noise)[0]) - base) <= 1e-6 * abs(base)
 
 
+def test_reference_dataloader_batch_feeds_forward_and_generate(pkg, tmp_path):
+    """the dict the reference's patch dataset yields ({'input','target','x_lr','x_hr','category',
+    'patient_id'}, collated by a torch DataLoader) goes through `model(v_in, v_gt)` and `model.generate` unchanged, and a
+    second program built from the same weights shares the packed weight images instead of re-packing."""
+    DC = importlib.import_module("video-to-video-diffusion_amd.data_contract")
+    model, sd, cfg = tiny_model_sd(pkg)
+    model.to(DEV)
+    g = torch.Generator().manual_seed(1)
+    for i in range(3):
+        torch.save({"input": torch.rand(1, 6, 48, 40, generator=g) * 2 - 1, "target": torch.rand(1, 36, 48, 40, generator=g) * 2 - 1,
+                    "category": "APE" if i % 2 else "non-APE", "patient_id": f"case_{i:04d}"}, tmp_path / f"case_{i:04d}.pt")
+
+    class PatchSet(torch.utils.data.Dataset):            # the reference dataset's __getitem__, positions fixed
+        files = sorted(tmp_path.glob("case_*.pt"))
+
+        def __len__(self):
+            return len(self.files)
+
+        def __getitem__(self, idx):
+            c = DC.read_patient_cache(self.files[idx])
+            tp, hp = DC.aligned_patch(c["thick"], c["thin"], 6 * idx, 4 * idx, 4, depth_thin=12, depth_thick=2, patch_hw=(32, 32))
+            return DC.make_item(tp, hp, c["category"], c["patient_id"])
+
+    loader = torch.utils.data.DataLoader(PatchSet(), batch_size=3, shuffle=False)
+    batch = next(iter(loader))
+    assert set(batch) == set(DC.ITEM_KEYS) and tuple(batch["input"].shape) == (3, 1, 2, 32, 32)
+    v_in, v_gt = DC.unpack_batch(batch, DEV)
+    loss, metrics = model(v_in, v_gt)
+    loss.backward()
+    assert torch.isfinite(loss) and model.unet.conv_in.weight.grad is not None
+    out = model.generate(v_in, 'ddim', num_inference_steps=3, target_depth=12)
+    assert tuple(out.shape) == tuple(v_gt.shape) and torch.isfinite(out).all()
+    # packed-weight cache: the sampler program of generate() packed every conv once; the plain-forward program of the
+    # same U-Net (another shape, another program) finds all its images in the cache
+    progs = model.unet.__dict__["_ctsi_programs"]
+    samp = [p_ for k_, p_ in progs.items() if k_[0] == "sampler"][0]
+    n_layers = samp.pack_stats["packed"] + samp.pack_stats["shared"]     # (images may already exist: the cache is
+    assert n_layers > 0                                                  # content-addressed across model instances)
+    z = torch.randn(3, 8, 12, 8, 8, device=DEV)
+    model.unet(z, torch.tensor([5, 6, 7], device=DEV), z)
+    fwd = [p_ for k_, p_ in model.unet.__dict__["_ctsi_programs"].items() if k_[0] == "unet"][0]
+    assert fwd.pack_stats["packed"] == 0 and fwd.pack_stats["shared"] == n_layers
+
+
 def test_training_loss_latent4_three_levels(pkg):
     """The 163 M-variant's shape family (latent_dim 4 -> 8-channel padded input / output-gradient tensors, 3 levels,
     attention at two levels, 8 heads, odd spatial sizes at the coarsest level) straight through

@@ -214,3 +214,40 @@ def test_utils_dropin_checkpoint_helpers(tmp_path, pkg):
     log = setup_logger("ctsi_test", log_file=str(tmp_path / "logs" / "x.log"))
     log.info("hello")
     assert "hello" in open(tmp_path / "logs" / "x.log").read()
+
+
+def test_dataset_tensor_contract(tmp_path, pkg):
+    """The reference's patient cache -> dataset item -> collated batch, rebuilt with the contract helpers, has exactly
+    the keys / shapes / values the reference's dataset code produces (data/patch_slice_interpolation_dataset.py:118-196,
+    257-274 restated inline below), and `unpack_batch` hands out the trainer's (v_in, v_gt)."""
+    import importlib
+    DC = importlib.import_module("video-to-video-diffusion_amd.data_contract")
+    g = torch.Generator().manual_seed(0)
+    thick = torch.rand(1, 10, 64, 48, generator=g) * 2 - 1
+    thin = torch.rand(1, 60, 64, 48, generator=g) * 2 - 1
+    torch.save({"thick": thick, "thin": thin, "category": "APE", "patient_id": "case_0001"}, tmp_path / "case_0001.pt")
+    torch.save({"input": thick, "target": thin}, tmp_path / "case_0002.pt")
+    c1, c2 = DC.read_patient_cache(tmp_path / "case_0001.pt"), DC.read_patient_cache(tmp_path / "case_0002.pt")
+    assert torch.equal(c1["thick"], thick) and torch.equal(c2["thin"], thin)
+    assert c1["category"] == "APE" and c2["category"] == "unknown"
+    z, y0, x0 = 13, 5, 9
+    tp, hp = DC.aligned_patch(c1["thick"], c1["thin"], z, y0, x0, depth_thin=12, depth_thick=2, patch_hw=(32, 24))
+    # the reference's arithmetic, restated: thin window, thick index = thin index * D_thick / D_thin, trilinear resample
+    ref_thin = thin[:, z:z + 12, y0:y0 + 32, x0:x0 + 24]
+    k0, k1 = int(z * 10 / 60), int((z + 12) * 10 / 60)
+    ref_thick = torch.nn.functional.interpolate(thick[:, k0:k1, y0:y0 + 32, x0:x0 + 24].unsqueeze(0), size=(2, 32, 24),
+                                                mode="trilinear", align_corners=False).squeeze(0)
+    assert torch.equal(hp, ref_thin) and torch.equal(tp, ref_thick)
+    assert tuple(tp.shape) == (1, 2, 32, 24) and tuple(hp.shape) == (1, 12, 32, 24)
+    tp2, hp2 = DC.aligned_patch(thick, thin[:, :7], 0, 0, 0, depth_thin=12, depth_thick=2, patch_hw=(32, 24))
+    assert tuple(hp2.shape) == (1, 12, 32, 24) and float(hp2[:, 7:].max()) == -1.0        # shallow volume: padded with air
+    items = [DC.make_item(tp, hp, "APE", "case_0001"), DC.make_item(tp.flip(2), hp.flip(2), "non-APE", "case_0002")]
+    assert all(tuple(it) == DC.ITEM_KEYS for it in items)
+    batch = torch.utils.data.default_collate(items)
+    assert tuple(batch["input"].shape) == (2, 1, 2, 32, 24) and batch["category"] == ["APE", "non-APE"]
+    v_in, v_gt = DC.unpack_batch(batch)
+    assert torch.equal(v_in, batch["x_lr"]) and torch.equal(v_gt, batch["x_hr"]) and v_in.dtype == torch.float32
+    with pytest.raises(ValueError, match="multiples of 4"):
+        DC.unpack_batch({"input": torch.zeros(1, 1, 2, 30, 24), "target": torch.zeros(1, 1, 12, 30, 24)})
+    with pytest.raises(ValueError, match="needs 'input' and 'target'"):
+        DC.unpack_batch({"category": ["x"]})

@@ -32,6 +32,7 @@ from .lib import CtsiError, WgradDesc
 class UNetTrainProgram(Program):
     def __init__(self, ctx: Ctx, unet, n: int, d: int, h: int, w: int):
         super().__init__(ctx)
+        self.weight_cache = False    # weights change every optimizer step: private images, repacked in place
         if unet.attention_mode != "fast":
             raise CtsiError("training supports attention_mode='fast' only")
         self.unet = unet

@@ -333,35 +333,43 @@ conv3_halo_kernel(const Conv3HaloParams p) {
 // port for 8 of its 16 cycles, the 32x32x16 form for 8 of 32), used whenever W >= 32-ish.
 // =====================================================================================================
 
-// Tile shapes: <2,32> = 4 x 2 x 32 voxels (an A tile of 32 rows = one W-line) and <4,16> = 4 x 4 x 16 voxels for 16-wide
-// levels (an A tile = two W-lines of 16: lanes 16-31 read the next H line), so that the 48 x 16 x 16 level runs on
-// 32x32x16 MFMAs with half the LDS reads per flop of conv3_halo_kernel's 16x16x32 form.
-template <int TH_, int TW_>
+// Tile shapes <TD, TH, TW, TM, TN> (TM x TN = 32x32 MFMA tiles per wave; 8 waves = WM x WN with WM * TM * 32 = BM rows and
+// WN * TN * 32 = 128 couts):
+//   <4,2,32,2,2> = 4 x 2 x 32 voxels, an A tile of 32 rows = one W-line; waves 4 (M) x 2 (N), 2 x 2 tiles each;
+//   <4,4,16,2,2> = 4 x 4 x 16 voxels for 16-wide levels: an A tile = two W-lines of 16 (lanes 16-31 read the next H
+//                  line), so those levels run on 32x32x16 MFMAs with half the LDS reads per flop of the 16x16x32 form;
+//   <3,4,16,3,1> = 3 x 4 x 16 = 192 voxels, waves 2 (M) x 4 (N), 3 x 1 tiles each: a 48 x 16 x 16 level with 512 couts is
+//                  16 x 4 x 4 = 256 blocks -- one per CU -- where 256-voxel tiles give 192 blocks on 256 CUs.
+template <int TD_, int TH_, int TW_, int TM_, int TN_>
 struct H32Cfg {
-    static constexpr int TD = 4, TH = TH_, TW = TW_;
+    static constexpr int TD = TD_, TH = TH_, TW = TW_, TM = TM_, TN = TN_;
     static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
     static constexpr int HV = HD * HH * HW;               // <2,32>: 816 halo voxels, <4,16>: 648
     static constexpr int HALO_INSTR = (HV + 15) / 16;     // 51 / 41
     static constexpr int HALO_BYTES = HALO_INSTR * 1024;
-    static constexpr int BM = TD * TH * TW;               // 256
+    static constexpr int BM = TD * TH * TW;               // 256 / 192
     static constexpr int BN = 128;
+    static constexpr int WM = BM / (TM * 32), WN = BN / (TN * 32);
     static constexpr int LPT = 32 / TW;                   // W-lines per 32-row A tile
     static constexpr int WSLOT_BYTES = 3 * BN * 64;
     static constexpr int NTH = 512;
     static constexpr int OFF_W = 2 * HALO_BYTES;
     static constexpr int OFF_ROW = OFF_W + 2 * WSLOT_BYTES;
     static constexpr int OFF_CS = OFF_ROW + BM * 8;
-    static constexpr int LDS_BYTES = OFF_CS + 4 * BN * 8;  // 159744 <= 163840
+    static constexpr int LDS_BYTES = OFF_CS + WM * BN * 8;  // <4,2,32>: 159744 <= 163840
     static constexpr int NPIECE = (HALO_INSTR + 7) / 8;    // halo DMA instructions per wave and chunk (issued at g < NPIECE)
-    static_assert(BM == 256 && TH * TW == 64 && NPIECE <= 9 && LDS_BYTES <= 160 * 1024, "unsupported tile");
+    static_assert(WM * WN == 8 && BM % (TM * 32) == 0 && 32 % TW == 0 && NPIECE <= 9 && LDS_BYTES <= 160 * 1024 &&
+                      BM * BN * 2 <= OFF_W, "unsupported tile");
 };
 
-template <int TH_, int TW_>
+template <int TD_, int TH_, int TW_, int TM_, int TN_>
 __global__ void __launch_bounds__(512)
 conv3_halo32_kernel(const Conv3HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using Cfg = H32Cfg<TH_, TW_>;
+    using Cfg = H32Cfg<TD_, TH_, TW_, TM_, TN_>;
     constexpr int TD = Cfg::TD, TH = Cfg::TH, TW = Cfg::TW, HH = Cfg::HH, HW = Cfg::HW, HV = Cfg::HV, LPT = Cfg::LPT;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, WM = Cfg::WM, WN = Cfg::WN;
+    (void)TD;
     constexpr int HALO_INSTR = Cfg::HALO_INSTR, HALO_BYTES = Cfg::HALO_BYTES, BM = Cfg::BM, BN = Cfg::BN, NTH = Cfg::NTH;
     constexpr int WSLOT_BYTES = Cfg::WSLOT_BYTES, OFF_W = Cfg::OFF_W, OFF_ROW = Cfg::OFF_ROW, OFF_CS = Cfg::OFF_CS;
     constexpr int NPIECE = Cfg::NPIECE;
@@ -372,7 +380,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int bid = xcd_remap_h(blockIdx.x, gridDim.x);
     int mt, nt;
@@ -448,36 +456,41 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
 
     // fragment addressing: lane -> row r = lane & 31 of the 32-row operand tile, k-group hk = lane >> 5
     const int hk = lane >> 5, r = lane & 31;
-    const int va = (wm * HH + r / TW) * HW + r % TW;         // halo voxel of this lane's row in A tile 0 (ld = wm), before taps
-    const int rowb = wn * 64 + r;
+    int vline[TM];                                           // halo voxel of this lane's row in each of the wave's A tiles
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {                           // A tile = rows [(wm*TM + i)*32, +32) = LPT whole W-lines
+        const int line = (wm * TM + i) * LPT + r / TW;
+        vline[i] = ((line / TH) * HH + (line % TH)) * HW + r % TW;
+    }
+    const int rowb = wn * (TN * 32) + r;
     const int b_off = rowb * 64 + ((hk ^ ((rowb >> 2) & 3)) << 4);   // k-step 0; k-step 1 = ^32; n-tile 1 = +2048
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
 
-    bf16x8 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2], fa2[2][2], fb2[2][2];   // [tile][k-step]
+    bf16x8 fa0[TM][2], fb0[TN][2], fa1[TM][2], fb1[TN][2], fa2[TM][2], fb2[TN][2];   // [tile][k-step]
     const int S = nchunks * 9;
-    int boffj[2];
+    int boffj[TN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
         boffj[j] = j * 2048;
         asm volatile("" : "+v"(boffj[j]));
     }
 
 #define H32_LOAD(FA, FB, HBUF, WBUF, VS, KW)                                                                   \
     {                                                                                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
-            const int v_ = (VS) + i_ * (LPT * HW) + (KW);                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) {                                                    \
+            const int v_ = (VS) + vline[i_] + (KW);                                                            \
             const int o_ = v_ * 64 + ((hk ^ ((v_ >> 2) & 3)) << 4);                                            \
             FA[i_][0] = *reinterpret_cast<const bf16x8*>((HBUF) + o_);                                         \
             FA[i_][1] = *reinterpret_cast<const bf16x8*>((HBUF) + (o_ ^ 32));                                  \
         }                                                                                                      \
-        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) {                                                    \
             const int o_ = b_off + (KW) * (BN * 64) + boffj[j_];                                               \
             FB[j_][0] = *reinterpret_cast<const bf16x8*>((WBUF) + o_);                                         \
             FB[j_][1] = *reinterpret_cast<const bf16x8*>((WBUF) + (o_ ^ 32));                                  \
@@ -486,8 +499,8 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
 #define H32_MFMA(FA, FB)                                                                                       \
     {                                                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                         \
-        _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)       \
-            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) acc[i_][j_] =                                     \
+        _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)      \
+            _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] =                                    \
                 __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i_][k_], FB[j_][k_], acc[i_][j_], 0, 0, 0);         \
         __builtin_amdgcn_s_setprio(0);                                                                         \
     }
@@ -502,10 +515,16 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
 #define H32_PHASE(FAc, FBc, FAl, FBl, HBUF, WBUF, VS, KW, DOLOAD)                                              \
     {                                                                                                          \
         H32_LOAD(FAl, FBl, HBUF, WBUF, VS, KW);                                                                \
-        _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)       \
-            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) acc[i_][j_] =                                     \
+        _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)      \
+            _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) acc[i_][j_] =                                    \
                 __builtin_amdgcn_mfma_f32_32x32x16_bf16(FAc[i_][k_], FBc[j_][k_], acc[i_][j_], 0, 0, 0);       \
-        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                     \
+        /* NLD = 2 (TM + TN) ds_read_b128 spread over the NMF = 2 TM TN MFMA gaps (the first NLD - NMF gaps take two) */ \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2 * (TM + TN) - 2 * TM * TN; ++q_) {                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                 \
+        }                                                                                                      \
+        _Pragma("unroll") for (int q_ = 2 * (TM + TN) - 2 * TM * TN; q_ < 2 * TM * TN; ++q_) {                 \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                 \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
@@ -519,8 +538,8 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
     if (S > 1) issue_weights(1, OFF_W + WSLOT_BYTES);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    H32_LOAD(fa0, fb0, smem, smem + OFF_W, va, 0);
-    H32_LOAD(fa1, fb1, smem, smem + OFF_W, va, 1);
+    H32_LOAD(fa0, fb0, smem, smem + OFF_W, 0, 0);
+    H32_LOAD(fa1, fb1, smem, smem + OFF_W, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
 
     int cc = 0, g = 0;
@@ -529,7 +548,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
         const char* hbuf = smem + (cc & 1) * HALO_BYTES;
         const char* wbuf = smem + OFF_W + (s & 1) * WSLOT_BYTES;
         const int kd = g / 3, kh = g - kd * 3;
-        const int vs = va + (kd * HH + kh) * HW;
+        const int vs = (kd * HH + kh) * HW;
         H32_PHASE(fa0, fb0, fa2, fb2, hbuf, wbuf, vs, 2, true);
         // every wave has drained this step's weight slot; the weight DMA of the previous step has landed.
         // A halo piece issued in the previous step (the youngest VMEM op of this wave) may stay in flight
@@ -552,7 +571,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
         const char* hbuf2 = smem + (cc2 & 1) * HALO_BYTES;
         const char* wbuf2 = smem + OFF_W + ((s + 1) & 1) * WSLOT_BYTES;
         const int kd2 = g2 / 3, kh2 = g2 - kd2 * 3;
-        const int vs2 = va + (kd2 * HH + kh2) * HW;
+        const int vs2 = (kd2 * HH + kh2) * HW;
         __builtin_amdgcn_sched_barrier(0);
         H32_PHASE(fa1, fb1, fa0, fb0, hbuf2, wbuf2, vs2, 0, true);
         H32_PHASE(fa2, fb2, fa1, fb1, hbuf2, wbuf2, vs2, 1, true);
@@ -569,26 +588,26 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16 = 64 KB
     const bool want_sums = p.colsum != nullptr;
     const int lhi = lane >> 5, lcol = lane & 31;
-    unsigned vbits[2];
+    unsigned vbits[TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
         unsigned vb = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int row = (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhi;
+            const int row = (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhi;
             vb |= (unsigned)(s_rowoff[row] >= 0) << q;
         }
         vbits[i] = vb;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = wn * 64 + j * 32 + lcol;
+    for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 32 + lcol;
         const int co = n0 + col;
         const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bf16_t* trow = s_tile + ((wm * 2 + i) * 32 + 4 * lhi) * BN + col;
+        for (int i = 0; i < TM; ++i) {
+            bf16_t* trow = s_tile + ((wm * TM + i) * 32 + 4 * lhi) * BN + col;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const float v = acc[i][j][q] + bv;
@@ -613,7 +632,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
     if (want_sums && tid < BN) {
         float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < WM; ++q) {
             t1 += s_cs[(q * BN + tid) * 2 + 0];
             t2 += s_cs[(q * BN + tid) * 2 + 1];
         }
@@ -675,18 +694,23 @@ extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void*
         using C44 = H3Cfg<4, 4>;
         auto k44 = conv3_halo_kernel<4, 4>;
         hipFuncSetAttribute((const void*)k44, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C44::LDS_BYTES);
-        hipFuncSetAttribute((const void*)conv3_halo32_kernel<2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)H32Cfg<2, 32>::LDS_BYTES);
-        hipFuncSetAttribute((const void*)conv3_halo32_kernel<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)H32Cfg<4, 16>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)conv3_halo32_kernel<4, 2, 32, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)H32Cfg<4, 2, 32, 2, 2>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)conv3_halo32_kernel<4, 4, 16, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)H32Cfg<4, 4, 16, 2, 2>::LDS_BYTES);
+        hipFuncSetAttribute((const void*)conv3_halo32_kernel<3, 4, 16, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)H32Cfg<3, 4, 16, 3, 1>::LDS_BYTES);
         attr_done = true;
     }
     const int grid = hp->mtiles * hp->ntiles_n;
-    constexpr int lds_232 = H32Cfg<2, 32>::LDS_BYTES, lds_416 = H32Cfg<4, 16>::LDS_BYTES;
+    constexpr int lds_232 = H32Cfg<4, 2, 32, 2, 2>::LDS_BYTES, lds_416 = H32Cfg<4, 4, 16, 2, 2>::LDS_BYTES;
+    constexpr int lds_316 = H32Cfg<3, 4, 16, 3, 1>::LDS_BYTES;
     if (wide == 1)
-        hipLaunchKernelGGL((conv3_halo32_kernel<2, 32>), dim3(grid), dim3(512), lds_232, (hipStream_t)stream, *hp);
+        hipLaunchKernelGGL((conv3_halo32_kernel<4, 2, 32, 2, 2>), dim3(grid), dim3(512), lds_232, (hipStream_t)stream, *hp);
     else if (wide == 3)
-        hipLaunchKernelGGL((conv3_halo32_kernel<4, 16>), dim3(grid), dim3(512), lds_416, (hipStream_t)stream, *hp);
+        hipLaunchKernelGGL((conv3_halo32_kernel<4, 4, 16, 2, 2>), dim3(grid), dim3(512), lds_416, (hipStream_t)stream, *hp);
+    else if (wide == 4)
+        hipLaunchKernelGGL((conv3_halo32_kernel<3, 4, 16, 3, 1>), dim3(grid), dim3(512), lds_316, (hipStream_t)stream, *hp);
     else {
         using C44 = H3Cfg<4, 4>;
         auto k44 = conv3_halo_kernel<4, 4>;

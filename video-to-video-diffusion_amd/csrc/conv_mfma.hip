@@ -646,7 +646,7 @@ struct ctsi_conv_plan {
     int8_t pH[4], pW[4];
     int tap_margin[4], ad_min[4];
     int fast, dshift;
-    int h32_w16;    // halo3 == 2 only: 1 = 4x4x16 tile (two W-lines of 16 per A tile) instead of 4x2x32
+    int h32_w16;    // halo3 == 2 only: 1 = 4x4x16 tile (two W-lines of 16 per A tile), 2 = 3x4x16 tile, instead of 4x2x32
     int m512_w16;   // halo3 == 5 only: 2 = 4x8x16 tile instead of 4x4x32
     int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip); 5: 512-voxel tile
                 // (conv3_halo_m512.hip).  3 / 4 were the persistent-block and half-size-block experiments, now under
@@ -875,11 +875,16 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 pick = 5;
                 p->m512_w16 = 2;
             }
-            {   // 16-wide levels on the 32x32x16-MFMA kernel (4x4x16 tile) instead of conv3_halo_kernel's 16x16x32 form
-                const char* hw = getenv("CTSI_CONV_H32W16");   // "0" | "1" (tuning aid)
+            {   // 16-wide levels on the 32x32x16-MFMA kernel instead of conv3_halo_kernel's 16x16x32 form: tile 4x4x16 (256
+                // voxels) or 3x4x16 (192 voxels; 3x1 MFMA tiles per wave: 0.95 of the 2x2 form's efficiency) -- whichever
+                // fills the 256 CUs better (48x16x16 x 512 couts: 192 vs 256 blocks)
+                const char* hw = getenv("CTSI_CONV_H32W16");   // "0" | "1" | "2" (tuning aid)
                 if (pick == 1 && !(hw && !strcmp(hw, "0"))) {
                     pick = 2;
-                    p->h32_w16 = 1;
+                    p->h32_w16 = score(3, 4, 16, 0.95) > score(4, 4, 16, 1.0) ? 2 : 1;
+                    if (hw && !strcmp(hw, "1")) p->h32_w16 = 1;
+                    if (hw && !strcmp(hw, "2")) p->h32_w16 = 2;
+                    if (p->h32_w16 == 2) p->BM = 192;
                 }
             }
             p->halo3 = pick;
@@ -901,7 +906,7 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     } else if (p->halo3 == 5) {
         p->TD = 4; p->TH = 4; p->TW = 32;
     } else if (p->halo3 == 2) {
-        p->TD = 4; p->TH = p->h32_w16 ? 4 : 2; p->TW = p->h32_w16 ? 16 : 32;
+        p->TD = p->h32_w16 == 2 ? 3 : 4; p->TH = p->h32_w16 ? 4 : 2; p->TW = p->h32_w16 ? 16 : 32;
     } else if (p->halo3 == 6) {
         p->TD = 4; p->TH = 2; p->TW = 16;
     } else if (p->halo3) {
@@ -1093,7 +1098,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         if (p->halo3 == 6)
             return ctsi_conv3_head_launch(&h, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
         if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, p->m512_w16, stream);
-        return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? (p->h32_w16 ? 3 : 1) : 0, stream);
+        return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? (p->h32_w16 == 2 ? 4 : (p->h32_w16 ? 3 : 1)) : 0, stream);
     }
     CTSI_CHECK_ARG(!p->halo3, "ctsi_conv_fwd: the 3x3x3 halo-tile plan supports bf16 NDHWC output without activation");
     ConvKParams k;

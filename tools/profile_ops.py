@@ -16,6 +16,7 @@ ap.add_argument("--depth", type=int, default=48)
 ap.add_argument("--net", default="unet")
 ap.add_argument("--repeats", type=int, default=3)
 ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--enc-depth", type=int, default=8, help="--net enc: input slices (8 = thick volume, 48 = training target)")
 args = ap.parse_args()
 pkg = importlib.import_module("video-to-video-diffusion_amd")
 E = importlib.import_module("video-to-video-diffusion_amd.engine")
@@ -33,7 +34,7 @@ with ctx.scope():
     elif args.net == "dec":
         prog = E.VAEDecodeProgram(ctx, model.vae, 1, args.depth, args.hw // 4, args.hw // 4)
     else:
-        prog = E.VAEEncodeProgram(ctx, model.vae, 1, 8, args.hw, args.hw)
+        prog = E.VAEEncodeProgram(ctx, model.vae, args.batch, args.enc_depth, args.hw, args.hw)
     prog.run()
     prof = prog.profile_ops(repeats=args.repeats)
 torch.cuda.synchronize()

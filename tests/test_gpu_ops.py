@@ -222,6 +222,58 @@ def test_conv_linearity_and_zero_padding_property(G):
     assert torch.equal(y, bf16_round(ref))
 
 
+@pytest.mark.parametrize("dims,cin,cmid,cout,tb", [((1, 5, 9, 40), 64, 128, 128, True), ((2, 4, 8, 32), 32, 64, 256, False),
+                                                   ((1, 6, 8, 48), 128, 128, 64, True)])
+def test_normalise_on_load_is_bit_identical(G, monkeypatch, dims, cin, cmid, cout, tb):
+    """conv -> GroupNorm + SiLU (+ time bias) -> conv with the normalisation applied to the staged halo tile inside the second
+    conv (ctsi_conv_out.nin_*, the 512-voxel kernel) == the same chain with ctsi_gn_apply as its own pass: same arithmetic, same
+    bf16 rounding, bit for bit; ragged edges, batch 2, 16- and 32-wide tiles."""
+    import importlib
+    E = importlib.import_module("video-to-video-diffusion_amd.engine")
+    n, d, h, w = dims
+    x = bf16_round(formula_input((n, cin, d, h, w), 51))
+    w1 = bf16_round(_w((cmid, cin, 3, 3, 3), 52))
+    w2 = bf16_round(_w((cout, cmid, 3, 3, 3), 53))
+    b1, b2 = formula_input((cmid,), 54) * 0.1, formula_input((cout,), 55) * 0.1
+    gn = torch.nn.GroupNorm(8, cmid)
+    with torch.no_grad():
+        gn.weight.copy_(1.0 + 0.2 * formula_input((cmid,), 56))
+        gn.bias.copy_(0.1 * formula_input((cmid,), 57))
+    tbias = (formula_input((3 * n, cmid + 8), 58) * 0.3).to("cuda:0")     # rows x (offset 8 + cmid) : exercises off / stride
+    step = torch.tensor([1], dtype=torch.int32, device="cuda:0")
+    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
+    monkeypatch.setenv("CTSI_CONV_M512", "1")
+    outs, kinds = [], []
+    for fused in (True, False):
+        monkeypatch.setenv("CTSI_CONV_NORM_IN", "1" if fused else "0")     # (opt-in: measured slower end to end)
+        c = G.ctx()
+        with c.scope():
+            prog = E.Program(c)
+            a = G.to_act(prog, x)
+            c1, st = prog.conv("c1", lambda: w1, lambda: b1, a, None, cout=cmid, want_stats=True)
+            slot = prog.gn_finalize(c1, 8, st)
+            tbarg = (tbias, 8, cmid + 8, step) if tb else None
+            c2, st2 = prog.conv("c2", lambda: w2, lambda: b2, c1, None, cout=cout, want_stats=True,
+                                norm_in=(slot, gn.to("cuda:0"), True, tbarg))
+            slot2 = prog.gn_finalize(c2, 8, st2)
+            prog.finalize_layout()
+            prog.run()
+            outs.append((G.from_act(prog, c2).cpu(), prog._gn_sums[slot2:slot2 + n * 16].clone().cpu()))
+            kinds.append([m[0] for m in prog.op_meta])
+        torch.cuda.synchronize()
+    assert any(k.endswith("+gn_in") for k in kinds[0]) and "gn.apply" not in kinds[0]
+    assert "gn.apply" in kinds[1]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # and against torch on the same bf16-rounded operands
+    h1 = F.conv3d(x, w1, b1, padding=1)
+    h1 = bf16_round(h1)
+    hn = F.silu(F.group_norm(h1, 8, gn.weight.cpu(), gn.bias.cpu(), eps=gn.eps))
+    if tb:
+        hn = hn + tbias.cpu()[n:2 * n, 8:].reshape(n, cmid, 1, 1, 1)
+    ref = F.conv3d(bf16_round(hn), w2, b2, padding=1)
+    assert rel_l2(outs[0][0], ref) < 6e-3
+
+
 def test_groupnorm_statistics_are_bit_stable(G):
     """ctsi_gn_finalize has no atomics: one block per (sample, group), fixed-order reduce -> the fp64 (sum, sumsq) are
     bit-identical from run to run, also with thousands of tile partials."""

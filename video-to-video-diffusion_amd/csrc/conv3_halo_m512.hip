@@ -57,7 +57,7 @@ __device__ __forceinline__ void hm_wait_vm(int allowed) {   // wave-uniform `all
     }
 }
 
-template <int TD_, int TH_, int TW_ = 32>
+template <int TD_, int TH_, int TW_ = 32, bool NIN = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, HmCfg<TD_, TH_, TW_>::NTH)))
 conv3_halo32m_kernel(const Conv3HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -115,8 +115,10 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
         const int hd = v / (HH * HW), rem = v - hd * (HH * HW);
         const int hh = rem / HW, hw = rem - hh * HW;
         const int gd = d0 + p.dshift - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-        const bool ok = (j < HALO_INSTR) && (v < HV) && gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 &&
-                        gw < p.Wi;
+        bool ok = (j < HALO_INSTR) && (v < HV) && gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
+        // normalise-on-load of a depth-sharded input: a halo slice at a volume end holds zeros = the conv's zero padding, which
+        // must stay zero: treat it as out of volume (hardware zero fill, no normalisation)
+        if (NIN && ((p.nin_pad_lo && gd == 0) || (p.nin_pad_hi && gd == p.Di - 1))) ok = false;
         hrel[i] = ok ? ((gd - dlo) * p.Hi + gh) * p.Wi + gw : -1;
         hq16[i] = (unsigned)(((lane & 1) ^ ((v >> 3) & 1)) * 16);   // logical 8-channel half stored in this slot
     }
@@ -163,6 +165,63 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
             }
         }
         return cnt;
+    };
+
+    // ---- normalise-on-load --------------------------------------------------------------------------------------------------
+    // per-channel (scale, shift, time bias) tables behind the loop / epilogue buffers; every lane later rewrites, in place, the
+    // 16 bytes (8 channels) of each halo piece it DMA'd itself, once that piece has landed (covered by the wave's own vmcnt
+    // wait); the barrier that already separates "chunk landed" from "chunk read" publishes the result to the other waves.
+    constexpr bool nin = NIN;     // normalise-on-load is its own instantiation: the plain kernel carries none of it
+    float* s_nsc = reinterpret_cast<float*>(smem + Cfg::LDS_BYTES);
+    float* s_nsh = s_nsc + C1;
+    float* s_ntb = s_nsh + C1;
+    if (nin) {
+        const int cpg = C1 / p.nin_groups;
+        long long trow = nb;
+        if (p.nin_step_ptr) trow += (long long)(*p.nin_step_ptr) * p.nin_n_total;
+        for (int ch = tid; ch < C1; ch += NTH) {
+            const int gi = ch / cpg;
+            const double mean = p.nin_sums[((long long)nb * p.nin_groups + gi) * 2 + 0] / p.nin_count;
+            double var = p.nin_sums[((long long)nb * p.nin_groups + gi) * 2 + 1] / p.nin_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)p.nin_eps));
+            const float sc = p.nin_gamma[ch] * rstd;
+            s_nsc[ch] = sc;
+            s_nsh[ch] = p.nin_beta[ch] - (float)mean * sc;
+            s_ntb[ch] = p.nin_tbias ? p.nin_tbias[trow * p.nin_tb_stride + ch] : 0.0f;
+        }
+    }
+    const int nq8 = ((lane & 1) ^ ((lane >> 4) & 1)) * 8;   // first channel (within a 16-channel chunk) of this lane's 16 bytes:
+                                                            // the same for every piece (hq16 does not depend on the piece)
+    auto xform_piece = [&](int i, int hoff, int ccn) {
+        const int j = wave + NWAVE * i;
+        if (j >= HALO_INSTR) return;
+        int hsel = hrel[0];
+#pragma unroll
+        for (int q = 1; q < NPIECE; ++q) hsel = (i == q) ? hrel[q] : hsel;
+        if (hsel < 0) return;                               // zero padding stays zero
+        uint4* ptr = reinterpret_cast<uint4*>(smem + hoff + j * 1024 + lane * 16);
+        const uint4 raw = *ptr;
+        const int ch = ccn * 16 + nq8;
+        const float4 sc0 = *reinterpret_cast<const float4*>(s_nsc + ch), sc1 = *reinterpret_cast<const float4*>(s_nsc + ch + 4);
+        const float4 sh0 = *reinterpret_cast<const float4*>(s_nsh + ch), sh1 = *reinterpret_cast<const float4*>(s_nsh + ch + 4);
+        const float4 tb0 = *reinterpret_cast<const float4*>(s_ntb + ch), tb1 = *reinterpret_cast<const float4*>(s_ntb + ch + 4);
+        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+        const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+        const float tb[8] = {tb0.x, tb0.y, tb0.z, tb0.w, tb1.x, tb1.y, tb1.z, tb1.w};
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = __uint_as_float(w[k] << 16) * sc[2 * k] + sh[2 * k];
+            float b = __uint_as_float(w[k] & 0xffff0000u) * sc[2 * k + 1] + sh[2 * k + 1];
+            if (p.nin_silu) {
+                a = silu_f(a);
+                b = silu_f(b);
+            }
+            o[k] = pack_bf16x2(a + tb[2 * k], b + tb[2 * k + 1]);
+        }
+        *ptr = make_uint4(o[0], o[1], o[2], o[3]);
     };
 
     // fragment addressing: lane -> row r = lane & 31 of the 32-row operand tile, k-half hk = lane >> 5
@@ -218,6 +277,11 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     for (int s = 0; s < NWS; ++s)
         if (s < S) issue_weights(s);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nin) {
+        __syncthreads();             // the coefficient tables are complete
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) xform_piece(i, 0, 0);
+    }
     __syncthreads();
     HN_LOAD(fa0, fb0, smem, smem + OFF_W, 0, 0);
     HN_LOAD(fa1, fb1, smem, smem + OFF_W, 0, 1);
@@ -238,6 +302,11 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
             issued += issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);                                      \
         n_prev2 = n_prev1;                                                                                     \
         n_prev1 = issued;                                                                                      \
+        /* normalise-on-load: the piece issued at step g-3 is covered by the wait above (older than the two    \
+           most recent steps); its rewrite is published by the following barriers, the last one (g = 7) by     \
+           barrier(8), after which the next chunk is first read */                                             \
+        if (nin && wave < 4 && g >= 3 && g - 3 < NPIECE && cc + 1 < nchunks)                                   \
+            xform_piece(g - 3, ((cc + 1) & 1) * HALO_BYTES, cc + 1);                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
     for (int s = 0; s < S; ++s) {
@@ -260,6 +329,13 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
         __builtin_amdgcn_sched_barrier(0);
         HN_PHASE(fa1, fb1, fa0, fb0, hbuf2, wbuf2, vs2, 0);
         HN_PHASE(fa2, fb2, fa1, fb1, hbuf2, wbuf2, vs2, 1);
+        // normalise-on-load, second half of the waves: the SIMD partners of waves 0-3 rewrite their piece at the END of
+        // the step, so that one partner's VALU burst runs beside the other's MFMA phases instead of both stalling the
+        // matrix pipe at the same time (still before the next barrier, which publishes it)
+        if (nin && wave >= 4 && g >= 3 && g - 3 < NPIECE && cc + 1 < nchunks) {
+            xform_piece(g - 3, ((cc + 1) & 1) * HALO_BYTES, cc + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         g = g2;
         cc = cc2;
     }
@@ -376,16 +452,30 @@ extern "C" int ctsi_conv3_halo_c16_pack(const float* w, void* packed, int cout, 
 extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16 */, void* stream) {
     using C44 = HmCfg<4, 4>;
     using C48 = HmCfg<4, 8, 16>;
-    auto k44 = conv3_halo32m_kernel<4, 4>;
-    auto k48 = conv3_halo32m_kernel<4, 8, 16>;
+    auto k44 = conv3_halo32m_kernel<4, 4, 32, false>;
+    auto k48 = conv3_halo32m_kernel<4, 8, 16, false>;
+    auto k44n = conv3_halo32m_kernel<4, 4, 32, true>;
+    auto k48n = conv3_halo32m_kernel<4, 8, 16, true>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)k44, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C44::LDS_BYTES);
-        hipFuncSetAttribute((const void*)k48, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C48::LDS_BYTES);
+        hipFuncSetAttribute((const void*)k44, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k48, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k44n, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k48n, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     const int grid = hp->mtiles * hp->ntiles_n;
-    if (tile == 2)
+    const int extra = hp->nin_sums ? 3 * hp->C1 * (int)sizeof(float) : 0;   // normalise-on-load coefficient tables
+    if (C44::LDS_BYTES + extra > 160 * 1024 || C48::LDS_BYTES + extra > 160 * 1024) {
+        ctsi_set_error("conv3_halo32m: normalise-on-load tables for %d channels do not fit the LDS", hp->C1);
+        return CTSI_ERR_UNSUPPORTED;
+    }
+    if (hp->nin_sums) {
+        if (tile == 2)
+            hipLaunchKernelGGL(k48n, dim3(grid), dim3(C48::NTH), C48::LDS_BYTES + extra, (hipStream_t)stream, *hp);
+        else
+            hipLaunchKernelGGL(k44n, dim3(grid), dim3(C44::NTH), C44::LDS_BYTES + extra, (hipStream_t)stream, *hp);
+    } else if (tile == 2)
         hipLaunchKernelGGL(k48, dim3(grid), dim3(C48::NTH), C48::LDS_BYTES, (hipStream_t)stream, *hp);
     else
         hipLaunchKernelGGL(k44, dim3(grid), dim3(C44::NTH), C44::LDS_BYTES, (hipStream_t)stream, *hp);

@@ -964,6 +964,16 @@ extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) { return p ? p->ncl
 extern "C" int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* p) { return p ? p->tps : 0; }
 extern "C" int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* p) { return p ? p->CoutPad : 0; }
 extern "C" double ctsi_conv_plan_flops(const ctsi_conv_plan* p) { return p ? p->flops : 0.0; }
+extern "C" int ctsi_conv_plan_supports_norm_in(const ctsi_conv_plan* p) {
+    // the 512-voxel halo-tile kernel, one source, coefficient tables (3 floats per channel) within the LDS left over.
+    // OPT-IN (CTSI_CONV_NORM_IN=1): bit-identical to the separate GroupNorm pass, but measured SLOWER end to end -- the in-LDS
+    // rewrite costs ~158 us per 0.6 ms launch (its ~670-cycle read / VALU / write chain per piece sits on every wave's
+    // critical path; placing it on one SIMD partner at a time hides none of it) against 69 us saved per skipped gn_apply:
+    // +0.9 ms per step.  Kept for a future version that interleaves the rewrite with the MFMA phases instruction by
+    // instruction (profiles/r02_notes.md).
+    const char* on = getenv("CTSI_CONV_NORM_IN");
+    return p && p->halo3 == 5 && p->d.c2 == 0 && p->d.c1 <= 1024 && on && atoi(on) == 1 ? 1 : 0;
+}
 extern "C" int ctsi_conv_plan_config(const ctsi_conv_plan* p, int* bm, int* bn, int* mode) {
     CTSI_CHECK_ARG(p, "ctsi_conv_plan_config: null plan");
     if (bm) *bm = p->BM;
@@ -1058,6 +1068,12 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
                        "ctsi_conv_fwd: bf16 output needs cout, cout_stride, c_off multiples of 8 "
                        "(cout=%d stride=%d off=%d)", p->d.cout, o->cout_stride, o->c_off);
     }
+    if (o->nin_sums != nullptr) {
+        CTSI_CHECK_ARG(ctsi_conv_plan_supports_norm_in(p) && o->mode == 0 && o->act == 0,
+                       "ctsi_conv_fwd: this plan does not support normalise-on-load (see ctsi_conv_plan_supports_norm_in)");
+        CTSI_CHECK_ARG(o->nin_gamma && o->nin_beta && o->nin_groups > 0 && p->d.c1 % o->nin_groups == 0 && o->nin_count > 0,
+                       "ctsi_conv_fwd: bad normalise-on-load arguments (groups=%d, c1=%d)", o->nin_groups, p->d.c1);
+    }
     if (o->gn_x != nullptr) {
         CTSI_CHECK_ARG(!p->halo3 && o->mode == 0 && o->act == 0 && o->colsum == nullptr && p->nclass == 1,
                        "ctsi_conv_fwd: the fused GroupNorm tail needs a gather-kernel plan, bf16 output, no act / colsum");
@@ -1095,6 +1111,19 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
         }
+        h.nin_sums = o->nin_sums;
+        h.nin_gamma = o->nin_gamma;
+        h.nin_beta = o->nin_beta;
+        h.nin_tbias = o->nin_tbias;
+        h.nin_step_ptr = o->nin_step_ptr;
+        h.nin_tb_stride = o->nin_tb_stride;
+        h.nin_groups = o->nin_groups;
+        h.nin_silu = o->nin_silu;
+        h.nin_n_total = p->d.n;
+        h.nin_pad_lo = o->nin_pad_lo;
+        h.nin_pad_hi = o->nin_pad_hi;
+        h.nin_eps = o->nin_eps;
+        h.nin_count = (double)o->nin_count;
         if (p->halo3 == 6)
             return ctsi_conv3_head_launch(&h, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
         if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, p->m512_w16, stream);

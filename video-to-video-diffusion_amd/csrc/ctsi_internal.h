@@ -88,6 +88,18 @@ struct Conv3HaloParams {
     int cout_stride, c_off;
     int n_major;          // block order inside an XCD: 1 = all m-tiles of one n-tile first (see h3_decode_tile)
     int dbg;              // timing-only ablation bits (0 in production): 1 no halo DMA after chunk 0, 2 no weight DMA after step 1
+    // normalise-on-load (conv3_halo32m_kernel, single source): the input is the RAW output of the previous conv; the kernel
+    // applies y = silu?(x * gamma * rstd + (beta - mean * gamma * rstd)) + tbias to every halo-tile element in LDS right after
+    // its DMA has landed, i.e. the GroupNorm + SiLU + time-bias pass between two convs never touches HBM.
+    const double* nin_sums;   // [n][groups][2] fp64 (sum, sumsq) of the input; NULL = plain input
+    const float* nin_gamma;
+    const float* nin_beta;
+    const float* nin_tbias;   // [rows][tb_stride] or NULL; row = (*nin_step_ptr) * n_total + sample
+    const int* nin_step_ptr;
+    int nin_tb_stride, nin_groups, nin_silu, nin_n_total;
+    int nin_pad_lo, nin_pad_hi;   // depth-sharded input: the first / last halo slice is a volume end (reads as zero padding)
+    float nin_eps;
+    double nin_count;
 };
 
 extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,

@@ -319,12 +319,23 @@ class Program:
     def conv(self, name: str, weight_fn, bias_fn, x1: Act, x2: Optional[Act], *, transposed=False,
              k=(3, 3, 3), s=(1, 1), p=(1, 1, 1), cout: int, cin_w: Optional[int] = None,
              out: Optional[Act] = None, want_stats=False, f32_out: Optional[torch.Tensor] = None,
-             f32_strides: Optional[Sequence[int]] = None, act: int = 0, fuse_gn=None, ext_out: bool = False):
+             f32_strides: Optional[Sequence[int]] = None, act: int = 0, fuse_gn=None, ext_out: bool = False,
+             norm_in=None):
         """Emit one convolution.  weight_fn/bias_fn return the *current* fp32 parameter tensors
         (possibly derived, e.g. scaled or pre-multiplied).  Returns (out_act, stats_handle).
         `fuse_gn` = (h: Act, slot, gn: nn.GroupNorm, silu: bool): the epilogue stores silu?(gn(h) + conv result)
-        instead of the conv result (ctsi_conv_out.gn_x; h may be the output buffer itself)."""
+        instead of the conv result (ctsi_conv_out.gn_x; h may be the output buffer itself).
+        `norm_in` = (slot, gn: nn.GroupNorm, silu: bool, tb) with tb = None or (tbias, tbias_off, tbias_stride, step_ptr):
+        x1 is the RAW output of the previous conv and this conv's input is silu?(gn(x1)) + tbias.  Plans that support it
+        (the 512-voxel halo-tile kernel with CTSI_CONV_NORM_IN=1: opt-in, measured slower, see
+        ctsi_conv_plan_supports_norm_in) normalise on load -- the GroupNorm pass never touches HBM; otherwise (the default)
+        the normalisation is emitted as its own in-place pass first.  Either way x1 must not be used raw afterwards."""
         lib = self.lib
+        nin_synced = False
+        if norm_in is not None and self.shard is not None and x1.halo:
+            # depth-sharded: statistics + RAW boundary slices in one sync point, whichever way the normalisation happens
+            self.sync_stats_and_halos(x1, norm_in[0], x1.n * norm_in[1].num_groups * 2)
+            nin_synced = True
         deep = k[0] > 1 and x1.halo == 1   # depth taps read the halo slices: "valid" conv along depth
         if x1.halo and x1.n != 1:
             raise CtsiError("a depth-sharded program holds one volume (batches run volume by volume, see "
@@ -348,6 +359,11 @@ class Program:
         self.plans.append(plan)
         if cin_w is not None:
             lib.conv_plan_set_weight_cin(plan, cin_w)
+        if norm_in is not None and not (x2 is None and lib.conv_plan_supports_norm_in(plan)):
+            nslot, ngn, nsilu, ntb = norm_in      # unfused: normalise in place, then a plain conv
+            kw_tb = {} if ntb is None else dict(tbias=ntb[0], tbias_off=ntb[1], tbias_stride=ntb[2], step_ptr=ntb[3])
+            self.gn_apply(x1, nslot, ngn, silu_pre=nsilu, out=x1, synced=nin_synced, **kw_tb)
+            norm_in = None
         do, ho, wo = C.c_int(), C.c_int(), C.c_int()
         lib.conv_plan_out_dims(plan, C.byref(do), C.byref(ho), C.byref(wo))
         do, ho, wo = do.value, ho.value, wo.value
@@ -412,6 +428,22 @@ class Program:
             co.c_off = 0
             out_act = out
         co.act = act
+        nin_slot = None
+        if norm_in is not None:
+            nin_slot, ngn, nsilu, ntb = norm_in
+            ngamma = self.dev_f32(lambda: ngn.weight)
+            nbeta = self.dev_f32(lambda: ngn.bias)
+            world = self.shard.world if (self.shard is not None and x1.halo) else 1
+            co.nin_gamma, co.nin_beta = ngamma.data_ptr(), nbeta.data_ptr()
+            co.nin_groups, co.nin_eps, co.nin_silu = ngn.num_groups, float(ngn.eps), int(nsilu)
+            co.nin_count = (x1.c // ngn.num_groups) * x1.d * world * x1.h * x1.w
+            if ntb is not None:
+                co.nin_tbias = ntb[0].data_ptr() + ntb[1] * 4
+                co.nin_tb_stride = ntb[2]
+                co.nin_step_ptr = 0 if ntb[3] is None else ntb[3].data_ptr()
+            if deep and self.shard is not None:
+                co.nin_pad_lo = int(self.shard.rank == 0)
+                co.nin_pad_hi = int(self.shard.rank == self.shard.world - 1)
         if fuse_gn is not None:
             gh, gslot, gmod, gsilu = fuse_gn
             if f32_out is not None or want_stats or (gh.n, gh.c, gh.d, gh.h, gh.w) != (x1.n, cout, out.d, ho, wo):
@@ -435,9 +467,13 @@ class Program:
             co.colsum = prog._colsum.data_ptr() if want_stats else 0
             if gn_slot is not None:
                 co.gn_sums = prog._gn_sums.data_ptr() + gn_slot * 8
+            if nin_slot is not None:
+                co.nin_sums = prog._gn_sums.data_ptr() + nin_slot * 8
             lib.conv_fwd(plan, x1p, x2p, _ptr(holder[0]), bp, C.byref(co), sptr)
 
         kernel = "conv_mfma_%dx%d_m%d" % (bm.value, bn.value, mode.value)
+        if norm_in is not None:
+            name = name + "+gn_in"
         self._emit(run, name, fl, kernel)
         return out_act, stats
 
@@ -525,11 +561,11 @@ class Program:
         c1, st = self.conv("rb.conv1", lambda: m.conv1.conv.weight, lambda: m.conv1.conv.bias, x, skip,
                            cout=cout, want_stats=True)
         slot = self.gn_finalize(c1, m.conv1.norm.num_groups, st)
-        h1 = self.gn_apply(c1, slot, m.conv1.norm, silu_pre=True, tbias=tbias, tbias_off=tbias_off,
-                           tbias_stride=tbias_stride, step_ptr=step_ptr, out=c1)
-        c2, st = self.conv("rb.conv2", lambda: m.conv2[0].weight, lambda: m.conv2[0].bias, h1, None, cout=cout,
-                           want_stats=True)
-        self.release(h1)
+        # conv2 consumes silu(gn(c1)) + time bias: normalised on load where the plan supports it (c1 is never rewritten)
+        c2, st = self.conv("rb.conv2", lambda: m.conv2[0].weight, lambda: m.conv2[0].bias, c1, None, cout=cout,
+                           want_stats=True,
+                           norm_in=(slot, m.conv1.norm, True, (tbias, tbias_off, tbias_stride, step_ptr)))
+        self.release(c1)
         slot = self.gn_finalize(c2, m.conv2[1].num_groups, st)
         if not has_res_conv:
             return self.gn_apply(c2, slot, m.conv2[1], silu_pre=False, residual=x, silu_post=True, out=c2)
@@ -945,10 +981,9 @@ class VAEEncodeProgram(Program):
         c1, st = self.conv("rb.conv1", lambda: m.conv1.conv.weight, lambda: m.conv1.conv.bias, x, None,
                            cout=x.c, want_stats=True)
         slot = self.gn_finalize(c1, m.conv1.norm.num_groups, st)
-        h1 = self.gn_apply(c1, slot, m.conv1.norm, silu_pre=True, out=c1)
-        c2, st = self.conv("rb.conv2", lambda: m.conv2[0].weight, lambda: m.conv2[0].bias, h1, None, cout=x.c,
-                           want_stats=True)
-        self.release(h1)
+        c2, st = self.conv("rb.conv2", lambda: m.conv2[0].weight, lambda: m.conv2[0].bias, c1, None, cout=x.c,
+                           want_stats=True, norm_in=(slot, m.conv1.norm, True, None))
+        self.release(c1)
         slot = self.gn_finalize(c2, m.conv2[1].num_groups, st)
         out = self.gn_apply(c2, slot, m.conv2[1], silu_pre=False, residual=x, silu_post=True, out=c2)
         self.release(x)

@@ -162,8 +162,10 @@ int ctsi_gn_colsum_tiles(int d, int h, int w);
 /* sums[n][g][2] (double) = sum over tiles/columns: WRITTEN, not accumulated (no zeroing needed), by one block per
  * (sample, group) with a fixed-order reduce -- bit-identical from run to run (no atomics).
  * nclass > 1: tiles of class k of sample i start at (k*n + i)*tiles_per_sample.          */
+/* accumulate != 0: sums += instead of sums = (a tensor produced by several conv launches -- the interior / boundary split
+ * of a depth-sharded conv -- is finalised slab by slab; still deterministic: the launches are ordered on the stream). */
 int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c, int c_pad, int groups,
-                     int tiles_per_sample, int nclass, void* stream);
+                     int tiles_per_sample, int nclass, int accumulate, void* stream);
 /* y = [silu]( gn(x)*gamma+beta ) [+ tbias[n][c]] [+ residual] ; [silu] again if silu_post */
 /* tbias row used for sample i: (step_ptr ? *step_ptr : 0) * n + i  (row length tbias_stride).
  * d_stat: depth the statistics in `sums` were accumulated over (== d on one GPU; the whole volume's
@@ -339,6 +341,8 @@ void ctsi_graph_destroy(ctsi_graph* graph);
 typedef struct ctsi_event ctsi_event;
 int ctsi_event_create(ctsi_event** ev);
 int ctsi_event_record(ctsi_event* ev, void* stream);
+/* device-side wait of `stream` for `ev` (no host sync; forks / joins a stream capture) */
+int ctsi_stream_wait_event(void* stream, ctsi_event* ev);
 int ctsi_event_elapsed_ms(ctsi_event* start, ctsi_event* stop, float* ms);
 void ctsi_event_destroy(ctsi_event* ev);
 

@@ -202,7 +202,10 @@ def test_rccl_transport_one_rank_eager_and_captured(pkg):
         ref.set_schedule([500])
         ref.run()
         eps_ref = ref.eps_ncdhw().cpu()
-        pr = E.UNetProgram(ctx, un, n, d, h, w, 4, shard=P.ShardSpec(0, 1, comm, d))
+        # overlap="force": also with one rank, the plain halo exchanges run on the second stream under the interior slices
+        # (event fork / join, inside the capture too)
+        pr = E.UNetProgram(ctx, un, n, d, h, w, 4, shard=P.ShardSpec(0, 1, comm, d, overlap="force"))
+        assert any(m[0] == "halo.exchange.async" for m in pr.op_meta) and any(m[0] == "halo.join" for m in pr.op_meta)
         pr.load_latents(x, c)
         pr.set_schedule([500])
         pr.run()

@@ -97,7 +97,7 @@ extern "C" int ctsi_gn_colsum(const void* x, float* colsum, int n, int c, int d,
 // scheduling), and the sums buffer needs no zeroing.
 __global__ void __launch_bounds__(1024)
 gn_finalize_kernel(const float* __restrict__ colsum, double* __restrict__ sums, int n_total, int c_pad,
-                   int groups, int cpg, int tps, int nclass) {
+                   int groups, int cpg, int tps, int nclass, int accumulate) {
     const int g = blockIdx.x, nb = blockIdx.y;
     const int tid = threadIdx.x;
     const long long slab = (long long)nclass * n_total * tps * c_pad;
@@ -139,18 +139,19 @@ gn_finalize_kernel(const float* __restrict__ colsum, double* __restrict__ sums, 
         __syncthreads();
     }
     if (tid == 0) {
-        sums[((long long)nb * groups + g) * 2 + 0] = s1[0];
-        sums[((long long)nb * groups + g) * 2 + 1] = s2[0];
+        double* o = sums + ((long long)nb * groups + g) * 2;
+        o[0] = (accumulate ? o[0] : 0.0) + s1[0];
+        o[1] = (accumulate ? o[1] : 0.0) + s2[0];
     }
 }
 
 extern "C" int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c, int c_pad, int groups,
-                                int tiles_per_sample, int nclass, void* stream) {
+                                int tiles_per_sample, int nclass, int accumulate, void* stream) {
     CTSI_CHECK_ARG(colsum && sums, "ctsi_gn_finalize: null argument");
     CTSI_CHECK_ARG(groups > 0 && c % groups == 0, "ctsi_gn_finalize: c=%d not divisible by groups=%d", c, groups);
     const int cpg = c / groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n), dim3(1024), 0, (hipStream_t)stream, colsum, sums, n, c_pad,
-                       groups, cpg, tiles_per_sample, nclass);
+                       groups, cpg, tiles_per_sample, nclass, accumulate);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

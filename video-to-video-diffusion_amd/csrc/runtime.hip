@@ -85,6 +85,13 @@ extern "C" int ctsi_event_record(ctsi_event* ev, void* stream) {
     CTSI_HIP(hipEventRecord(ev->ev, (hipStream_t)stream));
     return CTSI_OK;
 }
+// `stream` waits (on the device) for everything recorded into `ev`: cross-stream ordering without a host sync; inside a stream
+// capture it forks / joins the capture (the depth-sharded programs run the halo transfer on a second stream this way)
+extern "C" int ctsi_stream_wait_event(void* stream, ctsi_event* ev) {
+    CTSI_CHECK_ARG(ev, "ctsi_stream_wait_event: null event");
+    CTSI_HIP(hipStreamWaitEvent((hipStream_t)stream, ev->ev, 0));
+    return CTSI_OK;
+}
 extern "C" int ctsi_event_elapsed_ms(ctsi_event* a, ctsi_event* b, float* ms) {
     CTSI_CHECK_ARG(a && b && ms, "ctsi_event_elapsed_ms: null argument");
     CTSI_HIP(hipEventSynchronize(b->ev));

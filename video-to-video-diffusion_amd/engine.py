@@ -68,6 +68,12 @@ class Ctx:
             _CTX[idx] = Ctx(torch.device("cuda", idx))
         return _CTX[idx]
 
+    def comm_stream_ptr(self) -> C.c_void_p:
+        """The context's second HIP stream (created on first use): halo transfers that overlap interior compute."""
+        if getattr(self, "_comm_stream", None) is None:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        return C.c_void_p(self._comm_stream.cuda_stream)
+
     # make the engine stream wait for work queued on torch's current stream, and vice versa
     def enter(self):
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -340,6 +346,11 @@ class Program:
         if x1.halo and x1.n != 1:
             raise CtsiError("a depth-sharded program holds one volume (batches run volume by volume, see "
                             "sampler.run_sampler_sharded)")
+        if (deep and self.shard is not None and getattr(self.shard, "overlap", True)
+                and (self.shard.world > 1 or self.shard.overlap == "force")
+                and (x1.dirty or (x2 is not None and x2.dirty)) and x1.d >= 3 and not transposed and tuple(s) == (1, 1)
+                and f32_out is None and fuse_gn is None and norm_in is None and not ext_out and out is None and act == 0):
+            return self._conv_overlapped(name, weight_fn, bias_fn, x1, x2, k, p, cout, cin_w, want_stats)
         if deep:
             self.halo_exchange(x1)
             if x2 is not None:
@@ -477,6 +488,105 @@ class Program:
         self._emit(run, name, fl, kernel)
         return out_act, stats
 
+    def _conv_overlapped(self, name, weight_fn, bias_fn, x1: Act, x2: Optional[Act], k, p, cout, cin_w, want_stats):
+        """A depth-3 stride-1 conv whose input still needs its plain halo exchange (tensors no GroupNorm follows: conv_in /
+        Downsample / Upsample outputs, the sampler's updated input): the transfer runs on the context's second stream while
+        the INTERIOR output slices -- which read own slices only -- are computed; the two BOUNDARY slices follow the join
+        (SURVEY section 7-10).  Three launches of the same layer on three views of the same buffers:
+            interior  input = the d own slices taken as a halo'd tensor   -> output slices 1 .. d-2
+            lower     input = [lo halo, own 0, own 1]                     -> output slice 0
+            upper     input = [own d-2, own d-1, hi halo]                 -> output slice d-1"""
+        lib, sptr, prog, ctx = self.lib, self.ctx.sptr, self, self.ctx
+        spec = self.shard
+        cs = ctx.comm_stream_ptr()
+        ev_fork, ev_join = C.c_void_p(), C.c_void_p()
+        lib.event_create(C.byref(ev_fork))
+        lib.event_create(C.byref(ev_join))
+        self.keep.append((ev_fork, ev_join))
+        todo = [a for a in (x1, x2) if a is not None and a.halo and a.dirty]
+        sl = [self._slices(a) for a in todo]
+        for a in todo:
+            a.dirty = False
+
+        def run_fork():
+            lib.event_record(ev_fork, sptr)                 # the producer of the boundary slices is done ...
+            lib.stream_wait_event(cs, ev_fork)              # ... before the transfer starts, on the second stream
+            for (lo_own, hi_own, lo_halo, hi_halo) in sl:
+                spec.comm.exchange(spec.rank, lo_own, hi_own, lo_halo, hi_halo, sptr=cs)
+            lib.event_record(ev_join, cs)
+
+        self._emit(run_fork, "halo.exchange.async", 0.0, "comm")
+        d, se_in1 = x1.d, x1.slice_elems * 2
+        se_in2 = 0 if x2 is None else x2.slice_elems * 2
+        out = self.act(x1.n, cout, d, x1.h, x1.w, halo=x1.halo)
+        out.dirty = True
+        se_out = out.slice_elems * 2
+        bias = self.dev_f32(bias_fn) if bias_fn is not None else None
+        parts, col_off = [], 0
+        views = [("interior", d, x1.ip.value, 0 if x2 is None else x2.ip.value, out.ip.value + se_out),
+                 ("lower", 3, x1.fp.value, 0 if x2 is None else x2.fp.value, out.ip.value),
+                 ("upper", 3, x1.ip.value + (d - 2) * se_in1, 0 if x2 is None else x2.ip.value + (d - 2) * se_in2,
+                  out.ip.value + (d - 1) * se_out)]
+        for vi, (tag, di, p1, p2, py) in enumerate(views):
+            if vi == 1:
+                def run_join():
+                    lib.stream_wait_event(sptr, ev_join)    # halos have landed: the boundary slices may be computed
+                self._emit(run_join, "halo.join", 0.0, "comm.join")
+            desc = ConvDesc(0, k[0], k[1], k[2], 1, 1, p[0], p[1], p[2], x1.n, x1.c, 0 if x2 is None else x2.c, cout, di,
+                            x1.h, x1.w, 1)
+            plan = C.c_void_p()
+            lib.conv_plan_create(C.byref(plan), C.byref(desc))
+            self.plans.append(plan)
+            if cin_w is not None:
+                lib.conv_plan_set_weight_cin(plan, cin_w)
+            wbytes = lib.conv_plan_weight_bytes(plan)
+            bm, bn, mode = C.c_int(), C.c_int(), C.c_int()
+            lib.conv_plan_config(plan, C.byref(bm), C.byref(bn), C.byref(mode))
+            layout = "gather" if mode.value in (0, 2) else mode.value
+            sig = (layout, 0, tuple(k), (1, 1), x1.c, 0 if x2 is None else x2.c, cout, cin_w, lib.conv_plan_cout_pad(plan),
+                   wbytes)
+            holder: List[Optional[torch.Tensor]] = [None]
+
+            def pack(plan=plan, sig=sig, wbytes=wbytes, holder=holder):
+                wt = weight_fn().detach().to(device=prog.ctx.device, dtype=torch.float32).contiguous()
+                cache = _PACKED.setdefault(prog.ctx.device.index, weakref.WeakValueDictionary())
+                key = (sig, _content_key(wt))
+                t = cache.get(key)
+                if t is None:
+                    t = torch.empty(wbytes, dtype=torch.uint8, device=prog.ctx.device)
+                    lib.conv_plan_pack_weights(plan, _ptr(wt), _ptr(t), sptr)
+                    cache[key] = t
+                    prog.pack_stats["packed"] += 1
+                else:
+                    prog.pack_stats["shared"] += 1
+                wt.record_stream(prog.ctx.stream)
+                if holder[0] is not t:
+                    prog._weights_moved = prog._weights_moved or holder[0] is not None
+                    holder[0] = t
+
+            self.pack_fns.append(pack)
+            fl = lib.conv_plan_flops(plan)
+            self.flops += fl
+            self.conv_flops.append((name + "." + tag, fl))
+            co = ConvOut()
+            co.y, co.mode, co.cout_stride, co.c_off = py, 0, cout, 0
+            self.keep.append(co)
+            off = col_off
+            if want_stats:
+                tiles, cpad = lib.conv_plan_tiles(plan), lib.conv_plan_cout_pad(plan)
+                parts.append(dict(tps=lib.conv_plan_tiles_per_sample(plan), cpad=cpad, nclass=1, off=off))
+                col_off += 2 * tiles * cpad
+            bp = _ptr(bias)
+
+            def run(plan=plan, co=co, p1=p1, p2=p2, holder=holder, off=off):
+                co.colsum = (prog._colsum.data_ptr() + off * 4) if want_stats else 0
+                lib.conv_fwd(plan, C.c_void_p(p1), C.c_void_p(p2), _ptr(holder[0]), bp, C.byref(co), sptr)
+
+            self._emit(run, name + "." + tag, fl, "conv_mfma_%dx%d_m%d" % (bm.value, bn.value, mode.value))
+        if want_stats:
+            self._colsum_need = max(self._colsum_need, col_off)
+        return out, (dict(parts=parts) if want_stats else None)
+
     # ---- GroupNorm ----------------------------------------------------------------------------------------
     def _gn_slot(self, n, groups) -> int:
         off = self.gn_slots
@@ -484,15 +594,19 @@ class Program:
         return off
 
     def gn_finalize(self, x: Act, groups: int, stats: dict) -> int:
-        """colsum slab (already written by the producer) -> fp64 sums slot; returns the slot offset."""
+        """colsum slab(s) (already written by the producer) -> fp64 sums slot; returns the slot offset.  A tensor produced
+        by several launches (`stats["parts"]`: the interior / boundary split of a depth-sharded conv) is finalised slab by
+        slab, the later ones accumulating (ordered on the stream: still deterministic)."""
         slot = self._gn_slot(x.n, groups)
         lib, sptr, prog = self.lib, self.ctx.sptr, self
         n, c = x.n, x.c
-        tps, cpad, nclass = stats["tps"], stats["cpad"], stats["nclass"]
+        parts = stats.get("parts") or [dict(tps=stats["tps"], cpad=stats["cpad"], nclass=stats["nclass"], off=0)]
 
         def run():
-            lib.gn_finalize(_ptr(prog._colsum), C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), n, c, cpad,
-                            groups, tps, nclass, sptr)
+            for i, pt in enumerate(parts):
+                lib.gn_finalize(C.c_void_p(prog._colsum.data_ptr() + pt["off"] * 4),
+                                C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), n, c, pt["cpad"], groups, pt["tps"],
+                                pt["nclass"], int(i > 0), sptr)
 
         self._emit(run, "gn.finalize")
         # depth-sharded programs: the slot holds this slab's sums until `sync_stats_and_halos` (emitted by the consumer:

@@ -92,7 +92,7 @@ SIGNATURES = {
     "ctsi_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ConvOut), _vp], True),
     "ctsi_gn_colsum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _ip, _vp], True),
     "ctsi_gn_colsum_tiles": (_i, [_i, _i, _i], False),
-    "ctsi_gn_finalize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], True),
+    "ctsi_gn_finalize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_gn_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp,
                            _i, _vp], True),
     "ctsi_attn_depthsum": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], True),
@@ -145,6 +145,7 @@ SIGNATURES = {
     "ctsi_graph_destroy": (None, [_vp], False),
     "ctsi_event_create": (_i, [C.POINTER(_vp)], True),
     "ctsi_event_record": (_i, [_vp, _vp], True),
+    "ctsi_stream_wait_event": (_i, [_vp, _vp], True),
     "ctsi_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)], True),
     "ctsi_event_destroy": (None, [_vp], False),
 }

@@ -239,8 +239,9 @@ class LocalComm:
 class ShardSpec:
     rank: int
     world: int
-    comm: object          # DistComm | LocalComm
+    comm: object          # RcclComm | DistComm | LocalComm
     depth_total: int
+    overlap: bool = True  # plain halo exchanges run on a second stream under the interior slices of the consuming conv
 
     @property
     def depth_local(self) -> int:

@@ -9,8 +9,8 @@
 // with zero rows).  What bounds it then: every A fragment (1 KB per wave read) feeds a single 16-cycle MFMA, so the LDS
 // read rate is 27 x voxels x 2*Cin bytes (5.4 GB for the U-Net head) at 256 B/clk/CU -> ~45-70 us instead of 470.
 //
-// Block = 4 waves, output tile 4 x 2 x 16 voxels (8 W-lines, 2 per wave) x 16 couts; LDS = 27 KB halo + 27 KB weights
-// (single-buffered: two blocks share a CU, one computes while the other waits for its DMA) + row table + column sums.
+// Block = 4 waves, output tile 4 x 2 x 16 voxels (8 W-lines, 2 per wave) x 16 couts; LDS = 27 KB halo + 14 / 27 KB weights
+// (single-buffered: three / two blocks share a CU, one computes while the others wait for their DMA) + row table + sums.
 // Output: fp32 with arbitrary strides (+ optional tanh) or bf16 NDHWC, + per-tile GroupNorm column sums on request.
 #include "conv3_halo_common.h"
 
@@ -26,20 +26,30 @@ constexpr int HALO_BYTES = HALO_INSTR * 1024;
 constexpr int BM = TD * TH * TW;                 // 128
 constexpr int BN = 16;
 constexpr int NW = 4, NTH = 256;
-constexpr int WBYTES = 27 * BN * 64;             // 27 taps x 16 couts x 32 ch bf16 = 27 KB
-constexpr int OFF_W = HALO_BYTES;
-constexpr int OFF_ROW = OFF_W + WBYTES;
-constexpr int OFF_CS = OFF_ROW + BM * 8;
-constexpr int LDS_BYTES = OFF_CS + NW * BN * 8;  // 56832 B -> two blocks per CU
 constexpr int HPIECE = (HALO_INSTR + NW - 1) / NW;   // 7
-constexpr int WPIECE = (27 + NW - 1) / NW;           // 7
+// weight image per chunk: 27 taps x WR cout rows x 32 ch bf16.  WR = 8 when cout <= 8 (both network heads): lanes 8-15 of the
+// B operand re-read rows 0-7 (their output columns are never stored), which halves the weight slab -- 14 KB instead of 27 --
+// so THREE blocks share a CU instead of two: this kernel waits on HBM latency, and resident blocks are what hides it.
+template <int WR>
+struct Cfg {
+    static constexpr int WBYTES = (27 * WR * 64 + 1023) / 1024 * 1024;   // whole 1 KB DMA pieces: 14 KB / 27 KB
+    static constexpr int WINSTR = WBYTES / 1024;
+    static constexpr int WPIECE = (WINSTR + NW - 1) / NW;
+    static constexpr int OFF_W = HALO_BYTES;
+    static constexpr int OFF_ROW = OFF_W + WBYTES;
+    static constexpr int OFF_CS = OFF_ROW + BM * 8;
+    static constexpr int LDS_BYTES = OFF_CS + NW * BN * 8;   // 43.5 KB (WR 8) / 56.5 KB (WR 16)
+};
 }  // namespace hd3
 
+template <int WR>
 __global__ void __launch_bounds__(256)
 conv3_head_kernel(const Conv3HaloParams p, const int out_mode, const int act, const long long osn, const long long osc,
                   const long long osd, const long long osh, const long long osw) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using namespace hd3;
+    constexpr int OFF_W = Cfg<WR>::OFF_W, OFF_ROW = Cfg<WR>::OFF_ROW, OFF_CS = Cfg<WR>::OFF_CS;
+    constexpr int WINSTR = Cfg<WR>::WINSTR, WPIECE = Cfg<WR>::WPIECE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long* s_rowoff = reinterpret_cast<long long*>(smem + OFF_ROW);
     float* s_cs = reinterpret_cast<float*>(smem + OFF_CS);
@@ -103,7 +113,8 @@ conv3_head_kernel(const Conv3HaloParams p, const int out_mode, const int act, co
         const int line = wave * 2 + i;
         vline[i] = ((line / TH) * HH + (line % TH)) * HW + m;
     }
-    const int b_off = m * 64 + ((kg ^ ((m >> 2) & 3)) << 4) + half0;
+    const int mb = m & (WR - 1);                              // weight row of this lane (rows repeat when WR = 8)
+    const int b_off = mb * 64 + ((kg ^ ((mb >> 2) & 3)) << 4) + half0;
 
     f32x4 acc[2];
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -124,10 +135,10 @@ conv3_head_kernel(const Conv3HaloParams p, const int out_mode, const int act, co
         }
 #pragma unroll
         for (int i = 0; i < WPIECE; ++i) {
-            const int tap = wave + NW * i;
-            if (tap < 27) {
-                const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((cc * 27 + tap) * (BN * 64));
-                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + OFF_W + tap * 1024));
+            const int piece = wave + NW * i;                  // 1 KB = 16 / WR taps (the image is padded to whole pieces)
+            if (piece < WINSTR) {
+                const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(cc * (27 * WR * 64) + piece * 1024);
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + OFF_W + piece * 1024));
                 h3_dma16(rsw, dst, w_voff, soff);
             }
         }
@@ -141,7 +152,7 @@ conv3_head_kernel(const Conv3HaloParams p, const int out_mode, const int act, co
             const int vs = (kd * HH + kh) * HW;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const char* b_ = wbuf + (g * 3 + kw) * 1024;
+                const char* b_ = wbuf + (g * 3 + kw) * (WR * 64);
                 const uint2 blo = *reinterpret_cast<const uint2*>(b_);
                 const uint2 bhi = *reinterpret_cast<const uint2*>(b_ + ((half0 ^ 8) - half0));
                 const uint4 bu = make_uint4(blo.x, blo.y, bhi.x, bhi.y);
@@ -206,16 +217,15 @@ conv3_head_kernel(const Conv3HaloParams p, const int out_mode, const int act, co
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-extern "C" int ctsi_conv3_head_launch(const Conv3HaloParams* hp, int out_mode, int act, long long sn, long long sc,
+extern "C" int ctsi_conv3_head_launch(const Conv3HaloParams* hp, int rows, int out_mode, int act, long long sn, long long sc,
                                       long long sd, long long sh, long long sw, void* stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv3_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)hd3::LDS_BYTES);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(conv3_head_kernel, dim3(hp->mtiles), dim3(hd3::NTH), hd3::LDS_BYTES, (hipStream_t)stream, *hp,
-                       out_mode, act, sn, sc, sd, sh, sw);
+    constexpr int l8 = hd3::Cfg<8>::LDS_BYTES, l16 = hd3::Cfg<16>::LDS_BYTES;
+    if (rows == 8)
+        hipLaunchKernelGGL(conv3_head_kernel<8>, dim3(hp->mtiles), dim3(hd3::NTH), l8, (hipStream_t)stream, *hp, out_mode,
+                           act, sn, sc, sd, sh, sw);
+    else
+        hipLaunchKernelGGL(conv3_head_kernel<16>, dim3(hp->mtiles), dim3(hd3::NTH), l16, (hipStream_t)stream, *hp, out_mode,
+                           act, sn, sc, sd, sh, sw);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

@@ -957,6 +957,8 @@ extern "C" int ctsi_conv_plan_out_dims(const ctsi_conv_plan* p, int* d, int* h, 
 }
 extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
     if (!p) return 0;
+    if (p->halo3 == 6)   // head kernel: 8 weight rows when cout <= 8; + 1 KB: its last DMA piece is read whole
+        return (size_t)p->Cin * 27 * (p->d.cout <= 8 ? 8 : 16) * 2 + 1024;
     if (p->halo3) return (size_t)p->Cin * 27 * p->CoutPad * 2;   // [chunk][27][cout_pad][32 | 16 ch] bf16
     return (size_t)p->nclass * p->CoutPad * p->Ktot * 2;
 }
@@ -994,6 +996,10 @@ extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float*
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
     if (p->halo3 == 5) return ctsi_conv3_halo_c16_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
+    if (p->halo3 == 6) {
+        hipMemsetAsync((char*)packed + ctsi_conv_plan_weight_bytes(p) - 1024, 0, 1024, (hipStream_t)stream);
+        return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->d.cout <= 8 ? 8 : 16, p->Cin, p->CinW, stream);
+    }
     if (p->halo3) return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
     PackParams q;
     memset(&q, 0, sizeof(q));
@@ -1125,7 +1131,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         h.nin_eps = o->nin_eps;
         h.nin_count = (double)o->nin_count;
         if (p->halo3 == 6)
-            return ctsi_conv3_head_launch(&h, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
+            return ctsi_conv3_head_launch(&h, p->d.cout <= 8 ? 8 : 16, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
         if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, p->m512_w16, stream);
         return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? (p->h32_w16 == 2 ? 4 : (p->h32_w16 ? 3 : 1)) : 0, stream);
     }

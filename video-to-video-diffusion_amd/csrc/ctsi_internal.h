@@ -107,7 +107,7 @@ extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int 
 extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void* stream);
 extern "C" int ctsi_conv3_halo_c16_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
                                         void* stream);
-extern "C" int ctsi_conv3_head_launch(const Conv3HaloParams* hp, int out_mode, int act, long long sn, long long sc,
+extern "C" int ctsi_conv3_head_launch(const Conv3HaloParams* hp, int rows, int out_mode, int act, long long sn, long long sc,
                                       long long sd, long long sh, long long sw, void* stream);
 extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile, void* stream);
 

@@ -1,6 +1,7 @@
 """Interleaved A/B timing of one conv layer under two plan-selection environments (clock / thermal drift between
 separate processes is several percent on this part, so variants are alternated inside one process).
-    python tools/conv_ab.py CTSI_CONV_M512 0 62 --cin 512 --cout 512 --dhw 48 32 32"""
+    python tools/conv_ab.py CTSI_CONV_M512 0 1 --cin 512 --cout 512 --dhw 48 32 32
+(tools/ab_variants.py is the general form: any number of variants, several variables each)"""
 import argparse, importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

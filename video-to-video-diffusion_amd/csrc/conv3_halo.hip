@@ -559,9 +559,16 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < S && !(p.dbg & 2)) issue_weights(s + 2, OFF_W + (s & 1) * WSLOT_BYTES);
-        halo_in_flight = (g < NPIECE - 1) && (cc + 1 < nchunks) && !(p.dbg & 1) && (wave + 8 * g < HALO_INSTR);
-        if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1)) issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
+        // DMA issue placement: behind the first MFMA phase after the barrier (its 8 MFMAs drain through the matrix pipe while
+        // the pieces are issued) unless p.dbg & 16 (old placement, right behind the barrier: A/B timing)
+#define H32_ISSUE()                                                                                            \
+        {                                                                                                      \
+            if (s + 2 < S && !(p.dbg & 2)) issue_weights(s + 2, OFF_W + (s & 1) * WSLOT_BYTES);                \
+            halo_in_flight = (g < NPIECE - 1) && (cc + 1 < nchunks) && !(p.dbg & 1) && (wave + 8 * g < HALO_INSTR); \
+            if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1)) issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES); \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+        }
+        if (p.dbg & 16) H32_ISSUE();
         int g2 = g + 1, cc2 = cc;
         if (g2 == 9) {
             g2 = 0;
@@ -574,10 +581,12 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
         const int vs2 = (kd2 * HH + kh2) * HW;
         __builtin_amdgcn_sched_barrier(0);
         H32_PHASE(fa1, fb1, fa0, fb0, hbuf2, wbuf2, vs2, 0, true);
+        if (!(p.dbg & 16)) H32_ISSUE();
         H32_PHASE(fa2, fb2, fa1, fb1, hbuf2, wbuf2, vs2, 1, true);
         g = g2;
         cc = cc2;
     }
+#undef H32_ISSUE
 #undef H32_PHASE
 #undef H32_LOAD
 #undef H32_MFMA

@@ -1112,7 +1112,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             h.n_major = nm ? atoi(nm) : 0;
         }
         {
-            static const char* dbgf = getenv("CTSI_DEBUG_FLAGS");
+            const char* dbgf = getenv("CTSI_DEBUG_FLAGS");      // (read per launch: tools/ab_variants.py alternates them)
             h.dbg = dbgf ? atoi(dbgf) : 0;
             static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop

@@ -87,7 +87,9 @@ struct Conv3HaloParams {
     int Cout, CoutPad;
     int cout_stride, c_off;
     int n_major;          // block order inside an XCD: 1 = all m-tiles of one n-tile first (see h3_decode_tile)
-    int dbg;              // timing-only ablation bits (0 in production): 1 no halo DMA after chunk 0, 2 no weight DMA after step 1
+    int dbg;              // ablation bits (0 in production): 1 no halo DMA after chunk 0, 2 no weight DMA after step 1, 4 no
+                          // global stores, 8 no epilogue (1-8: wrong results, timing only); 16 / 32: DMA pieces issued right behind
+                          // the step's barrier / at the end of the step instead of behind the first MFMA phase (correct results)
     // normalise-on-load (conv3_halo32m_kernel, single source): the input is the RAW output of the previous conv; the kernel
     // applies y = silu?(x * gamma * rstd + (beta - mean * gamma * rstd)) + tbias to every halo-tile element in LDS right after
     // its DMA has landed, i.e. the GroupNorm + SiLU + time-bias pass between two convs never touches HBM.

@@ -64,6 +64,11 @@ def _worker(rank, world, port, out_dir):
         vol = full.reshape(1, 1, D, H * W, C)
         got = comm.gather_depth(rank, vol[:, :, slab.start:slab.stop].clone())
         assert torch.equal(got, vol)
+        # ragged slabs (depth 7 over the ranks): every rank sends max(counts) slices, the gather trims them
+        vol7 = torch.arange(7 * 5, dtype=torch.float32).reshape(1, 1, 7, 5, 1)
+        sl7 = P.depth_slab(7, rank, world)
+        counts = [len(P.depth_slab(7, r, world)) for r in range(world)]
+        assert torch.equal(comm.gather_depth(rank, vol7[:, :, sl7.start:sl7.stop].clone(), counts=counts), vol7)
         # data parallel: 5 independent volumes over 2 ranks -> 3 + 2, gathered back in order
         units = P.shard_units(5, rank, world)
         counts = [len(P.shard_units(5, r, world)) for r in range(world)]
@@ -125,8 +130,13 @@ def test_partitions():
     assert [list(P.shard_units(10, r, 4)) for r in range(4)] == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
     assert [len(P.shard_units(3, r, 8)) for r in range(8)] == [1, 1, 1, 0, 0, 0, 0, 0]
     assert list(P.depth_slab(48, 7, 8)) == list(range(42, 48))
+    # ragged slabs: the reference's real volumes are 50 thick -> 300 thin slices, 300 is not a multiple of 8
+    assert [len(P.depth_slab(300, r, 8)) for r in range(8)] == [38, 38, 38, 38, 37, 37, 37, 37]
+    assert P.depth_slab(300, 4, 8).start == 152 and P.depth_slab(300, 7, 8).stop == 300
+    spec = P.ShardSpec(5, 8, None, 300)
+    assert (spec.depth_local, spec.depth_start, sum(spec.depth_counts)) == (37, 189, 300)
     with pytest.raises(P.CtsiError):
-        P.depth_slab(50, 0, 8)
+        P.depth_slab(5, 0, 8)
 
 
 def test_local_comm_matches_dist_semantics():

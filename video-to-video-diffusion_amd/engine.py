@@ -348,7 +348,7 @@ class Program:
                             "sampler.run_sampler_sharded)")
         if (deep and self.shard is not None and getattr(self.shard, "overlap", True)
                 and (self.shard.world > 1 or self.shard.overlap == "force")
-                and (x1.dirty or (x2 is not None and x2.dirty)) and x1.d >= 3 and not transposed and tuple(s) == (1, 1)
+                and (x1.dirty or (x2 is not None and x2.dirty)) and min(self.shard.depth_counts) >= 3 and not transposed and tuple(s) == (1, 1)
                 and f32_out is None and fuse_gn is None and norm_in is None and not ext_out and out is None and act == 0):
             return self._conv_overlapped(name, weight_fn, bias_fn, x1, x2, k, p, cout, cin_w, want_stats)
         if deep:
@@ -444,10 +444,10 @@ class Program:
             nin_slot, ngn, nsilu, ntb = norm_in
             ngamma = self.dev_f32(lambda: ngn.weight)
             nbeta = self.dev_f32(lambda: ngn.bias)
-            world = self.shard.world if (self.shard is not None and x1.halo) else 1
+            d_stat = self.shard.depth_total if (self.shard is not None and x1.halo) else x1.d
             co.nin_gamma, co.nin_beta = ngamma.data_ptr(), nbeta.data_ptr()
             co.nin_groups, co.nin_eps, co.nin_silu = ngn.num_groups, float(ngn.eps), int(nsilu)
-            co.nin_count = (x1.c // ngn.num_groups) * x1.d * world * x1.h * x1.w
+            co.nin_count = (x1.c // ngn.num_groups) * d_stat * x1.h * x1.w
             if ntb is not None:
                 co.nin_tbias = ntb[0].data_ptr() + ntb[1] * 4
                 co.nin_tb_stride = ntb[2]
@@ -461,7 +461,7 @@ class Program:
                 raise CtsiError("internal: fused GroupNorm tail needs a bf16 output of the normalised tensor's shape")
             ggamma = self.dev_f32(lambda: gmod.weight)
             gbeta = self.dev_f32(lambda: gmod.bias)
-            d_stat = gh.d * (self.shard.world if (self.shard is not None and gh.halo) else 1)
+            d_stat = self.shard.depth_total if (self.shard is not None and gh.halo) else gh.d
             co.gn_x = self.ext_ptr(gh, ext_lo).value
             co.gn_gamma, co.gn_beta = ggamma.data_ptr(), gbeta.data_ptr()
             co.gn_groups, co.gn_eps = gmod.num_groups, float(gmod.eps)
@@ -651,7 +651,7 @@ class Program:
         stp = _ptr(step_ptr)
         rp = C.c_void_p(0) if residual is None else self.ext_ptr(residual, lo)
         n, c, h, w, groups, eps = x.n, x.c, x.h, x.w, gn.num_groups, float(gn.eps)
-        d_stat = x.d * (self.shard.world if (self.shard is not None and x.halo) else 1)  # statistics span all ranks
+        d_stat = self.shard.depth_total if (self.shard is not None and x.halo) else x.d   # statistics span all ranks
         d = d_ext
 
         def run():
@@ -716,7 +716,7 @@ class Program:
         depthsum = self.pool.get(n * h * w * c, torch.float32)
         xp, dsp = x.ip, _ptr(depthsum)
         world = self.shard.world if (self.shard is not None and x.halo) else 1
-        d_all = d * world
+        d_all = self.shard.depth_total if (self.shard is not None and x.halo) else d
 
         def run_ds():
             lib.attn_depthsum(xp, dsp, _ptr(prog._colsum), n, c, d, h, w, sptr)
@@ -968,7 +968,7 @@ class UNetProgram(Program):
         """Take (this rank's depth slab of) the fp32 NCDHW latent / conditioning into the engine layout."""
         lib, sptr = self.lib, self.ctx.sptr
         n, L, d, h, w = self.n, self.L, self.d, self.h, self.w
-        lo = 0 if self.shard is None else self.shard.rank * d
+        lo = 0 if self.shard is None else self.shard.depth_start
         if z_ncdhw is not None:
             z = z_ncdhw.detach()[:, :, lo:lo + d].to(device=self.ctx.device, dtype=torch.float32).contiguous()
             lib.ncdhw_f32_to_ndhwc_f32(_ptr(z), _ptr(self.z), n, L, d, h, w, sptr)
@@ -1167,7 +1167,7 @@ class VAEDecodeProgram(VAEEncodeProgram):
     def load(self, z: torch.Tensor):
         lib, sptr = self.lib, self.ctx.sptr
         self.ensure_fresh()
-        lo = 0 if self.shard is None else self.shard.rank * self.d
+        lo = 0 if self.shard is None else self.shard.depth_start
         zz = z.detach()[:, :, lo:lo + self.d].to(device=self.ctx.device, dtype=torch.float32).contiguous()
         lib.ncdhw_f32_to_ndhwc_bf16(_ptr(zz), self.zin.ip, self.n, self.L, self.d, self.h, self.w, self.L_pad, 0, sptr)
         zz.record_stream(self.ctx.stream)
@@ -1178,7 +1178,7 @@ class VAEDecodeProgram(VAEEncodeProgram):
             self.launch()
             return self.out.clone()
         self.run()
-        return self.shard.comm.gather_depth(self.shard.rank, self.out)
+        return self.shard.comm.gather_depth(self.shard.rank, self.out, counts=self.shard.depth_counts)
 
 
 # ==========================================================================================================

@@ -51,10 +51,11 @@ def gather_units(local: torch.Tensor, counts: Sequence[int], group=None) -> torc
 
 
 def depth_slab(depth: int, rank: int, world: int) -> range:
-    if depth % world != 0:
-        raise CtsiError(f"depth sharding needs depth ({depth}) divisible by the number of ranks ({world})")
-    q = depth // world
-    return range(rank * q, (rank + 1) * q)
+    """Contiguous depth slab of rank r: balanced, the first depth % world ranks own one slice more (300 thin slices over 8
+    GPUs = 38,38,38,38,37,37,37,37).  Every rank needs at least one slice."""
+    if depth < world:
+        raise CtsiError(f"depth sharding needs at least one slice per rank (depth {depth}, {world} ranks)")
+    return shard_units(depth, rank, world)
 
 
 # ---- communicators ---------------------------------------------------------------------------------------------
@@ -122,15 +123,19 @@ class RcclComm:
                                       0 if sums is None else sums.numel(), p(f32), 0 if f32 is None else f32.numel(),
                                       sptr)
 
-    def gather_depth(self, rank, slab, sptr=None):
+    def gather_depth(self, rank, slab, sptr=None, counts=None):
+        """`counts`: slices per rank when the slabs are ragged (every rank then sends max(counts) slices, zero padded)."""
         import ctypes as C
+        dmax = slab.shape[2] if counts is None else max(counts)
+        if slab.shape[2] != dmax:
+            slab = torch.cat([slab, slab.new_zeros(slab.shape[:2] + (dmax - slab.shape[2],) + slab.shape[3:])], dim=2)
         slab = slab.contiguous()
         out = torch.empty((self.world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
         if sptr is None:
             sptr = C.c_void_p(torch.cuda.current_stream(slab.device).cuda_stream)
         self.lib.comm_allgather(self.handle, C.c_void_p(slab.data_ptr()), C.c_void_p(out.data_ptr()),
                                 slab.numel() * slab.element_size(), sptr)
-        return torch.cat([out[r] for r in range(self.world)], dim=2)
+        return torch.cat([out[r][:, :, :(dmax if counts is None else counts[r])] for r in range(self.world)], dim=2)
 
     def __del__(self):
         try:
@@ -181,10 +186,13 @@ class DistComm:
     def all_reduce(self, rank: int, t: torch.Tensor):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
-    def gather_depth(self, rank: int, slab: torch.Tensor, sptr=None) -> torch.Tensor:
+    def gather_depth(self, rank: int, slab: torch.Tensor, sptr=None, counts=None) -> torch.Tensor:
+        dmax = slab.shape[2] if counts is None else max(counts)
+        if slab.shape[2] != dmax:
+            slab = torch.cat([slab, slab.new_zeros(slab.shape[:2] + (dmax - slab.shape[2],) + slab.shape[3:])], dim=2)
         outs = [torch.empty_like(slab) for _ in range(self.world)]
         self.dist.all_gather(outs, slab.contiguous(), group=self.group)
-        return torch.cat(outs, dim=2)
+        return torch.cat([o[:, :, :(dmax if counts is None else counts[r])] for r, o in enumerate(outs)], dim=2)
 
 
 class LocalComm:
@@ -228,7 +236,7 @@ class LocalComm:
     def all_reduce(self, rank: int, t: torch.Tensor):
         self.exchange(rank, None, None, None, None, sums=t)
 
-    def gather_depth(self, rank: int, slab: torch.Tensor, sptr=None):
+    def gather_depth(self, rank: int, slab: torch.Tensor, sptr=None, counts=None):
         items = self._arrive((rank, slab))
         if items is None:
             return None
@@ -246,6 +254,14 @@ class ShardSpec:
     @property
     def depth_local(self) -> int:
         return len(depth_slab(self.depth_total, self.rank, self.world))
+
+    @property
+    def depth_start(self) -> int:
+        return depth_slab(self.depth_total, self.rank, self.world).start
+
+    @property
+    def depth_counts(self) -> List[int]:
+        return [len(depth_slab(self.depth_total, r, self.world)) for r in range(self.world)]
 
 
 def run_lockstep(programs: Sequence, launches: int = 1):

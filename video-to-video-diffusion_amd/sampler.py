@@ -156,7 +156,7 @@ def run_sampler_sharded(diffusion, unet, shape, conditioning, ctx, z0, *, kind, 
         prog = cached_program(unet, key, build)
         coef = (ddim_coef_rows(diffusion.alphas_cumprod, t_desc, eta) if kind == "ddim"
                 else diffusion.ddpm_coef_rows(t_desc))
-        lo = comm.rank * dl
+        lo = spec.depth_start
         noises = {}
         for b in range(n):
             prog.load_latents(z0[b:b + 1], conditioning[b:b + 1])
@@ -172,8 +172,8 @@ def run_sampler_sharded(diffusion, unet, shape, conditioning, ctx, z0, *, kind, 
                     prog.noise.copy_(noises[i][b:b + 1, :, lo:lo + dl].to(ctx.device, torch.float32))
                 prog.launch() if capture else prog.run()
                 if trajectory is not None:
-                    trajs[i].append(comm.gather_depth(comm.rank, prog.z_ncdhw()))
-            outs.append(comm.gather_depth(comm.rank, prog.z_ncdhw()))
+                    trajs[i].append(comm.gather_depth(comm.rank, prog.z_ncdhw(), counts=spec.depth_counts))
+            outs.append(comm.gather_depth(comm.rank, prog.z_ncdhw(), counts=spec.depth_counts))
         if trajectory is not None:
             trajectory.extend(torch.cat(t, dim=0) for t in trajs)
         return torch.cat(outs, dim=0)

@@ -53,14 +53,18 @@ def test_conv_plan_geometry_and_flops(lib):
     assert abs(lib.conv_plan_flops(p) / 1e9 - 695.8) < 0.1
     bm, bn, mode = C.c_int(), C.c_int(), C.c_int()
     lib.conv_plan_config(p, C.byref(bm), C.byref(bn), C.byref(mode))
-    assert (bm.value, bn.value, mode.value) == (512, 128, 7)     # 3x3x3, W >= 32, 1536 blocks: LDS halo-tile kernel, 4x4x32 tile
+    assert (bm.value, bn.value, mode.value) == (512, 128, 9)     # 3x3x3, W >= 32, 1536 blocks: LDS halo-tile kernel, 4x4x32 tile,
+                                                                 # tap pairs on 16x16x32 MFMAs (conv3_halo_k32.hip)
     p2 = _plan(lib, c1=512, cout=512, hi=32, wi=32)              # 384 blocks of 512 voxels would leave CUs idle: 4x2x32 tile
     lib.conv_plan_config(p2, C.byref(bm), C.byref(bn), C.byref(mode))
     assert (bm.value, bn.value, mode.value) == (256, 128, 4)
     lib.conv_plan_destroy(p2)
     lib.conv_plan_config(p, C.byref(bm), C.byref(bn), C.byref(mode))
     assert lib.conv_plan_tiles(p) == 48 * 128 * 128 // bm.value and lib.conv_plan_cout_pad(p) == 128
-    assert lib.conv_plan_weight_bytes(p) == 128 * 27 * 128 * 2
+    assert lib.conv_plan_weight_bytes(p) == 128 * 27 * 128 * 2       # 8 chunks x 27 taps = 216 entries = 54 whole steps
+    p3 = _plan(lib, c1=16, cout=128)                                 # 27 entries -> padded to 28 (7 steps of 4)
+    assert lib.conv_plan_weight_bytes(p3) == 28 * 128 * 32
+    lib.conv_plan_destroy(p3)
     do, ho, wo = C.c_int(), C.c_int(), C.c_int()
     lib.conv_plan_out_dims(p, C.byref(do), C.byref(ho), C.byref(wo))
     assert (do.value, ho.value, wo.value) == (48, 128, 128)

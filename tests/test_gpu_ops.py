@@ -121,7 +121,7 @@ HALO3_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["16", "16h", "16h3", "16m", "32", "32m"])
+@pytest.mark.parametrize("tile", ["16", "16h", "16h3", "16m", "32", "32m", "16k", "32k"])
 @pytest.mark.parametrize("name,c1,c2,cout,dims", HALO3_CASES, ids=[c[0] for c in HALO3_CASES])
 def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     """The LDS halo-tile 3x3x3 kernel (conv3_halo.hip) on aligned, ragged, multi-tile and two-source inputs;
@@ -137,10 +137,12 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
     # "16": 4x4x16 tile (16x16x32 MFMA); "16h": 4x4x16 tile on the 32x32x16-MFMA kernel (two W-lines per A tile); "32":
     # 4x2x32 tile (32x32x16 MFMA); "32m" / "16m": the 512-voxel kernel in its 4x4x32 / 4x8x16 form.  (The measured-slower round-1 variants live under csrc/experiments/ and are not built in.)
-    monkeypatch.setenv("CTSI_CONV_HALO_TILE", "32" if tile == "16m" else tile[:2])   # ("16h3": the 192-voxel tile)
-    monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile == "16m" else "0")
+    # "32k" / "16k": the same 512-voxel tiles on 16x16x32 MFMAs over tap pairs (conv3_halo_k32.hip)
+    monkeypatch.setenv("CTSI_CONV_HALO_TILE", "32" if tile in ("16m", "16k") else tile[:2])   # ("16h3": the 192-voxel tile)
+    monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile in ("16m", "16k") else "0")
+    monkeypatch.setenv("CTSI_CONV_K32", "1" if tile in ("32k", "16k") else "0")
     monkeypatch.setenv("CTSI_CONV_H32W16", {"16h": "1", "16h3": "2"}.get(tile, "0"))    # 4x4x16 / 3x4x16 tiles
-    monkeypatch.setenv("CTSI_CONV_M512", "1" if tile in ("32m", "16m") else "0")
+    monkeypatch.setenv("CTSI_CONV_M512", "1" if tile in ("32m", "16m", "32k", "16k") else "0")
     y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=groups)
     assert rel_l2(y, ref) < CONV_TOL, name
     rg = ref.reshape(n, groups, -1).double()
@@ -243,6 +245,7 @@ def test_normalise_on_load_is_bit_identical(G, monkeypatch, dims, cin, cmid, cou
     step = torch.tensor([1], dtype=torch.int32, device="cuda:0")
     monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
     monkeypatch.setenv("CTSI_CONV_M512", "1")
+    monkeypatch.setenv("CTSI_CONV_K32", "0")        # both chains on conv3_halo32m_kernel, the one that implements the rewrite
     outs, kinds = [], []
     for fused in (True, False):
         monkeypatch.setenv("CTSI_CONV_NORM_IN", "1" if fused else "0")     # (opt-in: measured slower end to end)

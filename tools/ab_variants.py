@@ -12,6 +12,7 @@ ap.add_argument("variants", nargs="+")
 ap.add_argument("--cin", type=int, default=512); ap.add_argument("--cout", type=int, default=512)
 ap.add_argument("--dhw", type=int, nargs=3, default=[48, 32, 32]); ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--n", type=int, default=1); ap.add_argument("--f32", action="store_true")
+ap.add_argument("--zero", action="store_true", help="all-zero operands: cycles at the unthrottled clock (MI355X_MICROARCH.md, DVFS give-back)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 ctx = E.Ctx.get(dev)
@@ -23,7 +24,7 @@ for v in a.variants:
         if "=" in kv:
             names.add(kv.split("=")[0])
 with ctx.scope():
-    wt = torch.randn(a.cout, a.cin, 3, 3, 3, device=dev) * 0.02
+    wt = torch.randn(a.cout, a.cin, 3, 3, 3, device=dev) * (0.0 if a.zero else 0.02)
     b = torch.randn(a.cout, device=dev)
     for v in a.variants:
         for nme in names:
@@ -35,6 +36,8 @@ with ctx.scope():
         prog = E.Program(ctx)
         x = prog.act(a.n, a.cin, d, h, w)
         x.t.normal_()
+        if a.zero:
+            x.t.zero_()
         prog.zero_gn_op()
         if a.f32:
             y = prog.persistent((a.n, d, h, w, a.cout), torch.float32)

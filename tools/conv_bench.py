@@ -25,7 +25,9 @@ for name, cin, cout, (d, h, w), kind in CASES:
         prog = E.Program(ctx)
         x = prog.act(1, cin, d, h, w)
         x.t.normal_()
-        wt = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.02
+        if os.environ.get("CONV_ZERO") == "1":     # clock-vs-data check (MI355X_MICROARCH.md, DVFS give-back item 1)
+            x.t.zero_()
+        wt = torch.randn(cout, cin, 3, 3, 3, device=dev) * (0.0 if os.environ.get("CONV_ZERO") == "1" else 0.02)
         b = torch.randn(cout, device=dev)
         prog.zero_gn_op()
         y, st = prog.conv(name, lambda: wt, lambda: b, x, None, cout=cout, want_stats=stats)

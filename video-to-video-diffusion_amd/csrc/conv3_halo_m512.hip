@@ -298,7 +298,7 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
            s+1 (issued 3 steps ago); the next chunk's halo pieces are issued at g < NPIECE <= 6, so they are   \
            older than the two most recent steps' DMAs by the time they are read (g = 8). */                    \
         hm_wait_vm(n_prev1 + n_prev2);                                                                         \
-        __builtin_amdgcn_s_barrier();                                                                          \
+        if (!(p.dbg & 64)) __builtin_amdgcn_s_barrier();   /* (64: timing-only ablation) */                    \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
 #define HM_ISSUE()                                                                                             \

@@ -888,7 +888,15 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 }
             }
             p->halo3 = pick;
-            if (pick == 5) p->BM = 512;
+            if (pick == 5) {
+                p->BM = 512;
+                // the 512-voxel tile runs on v_mfma_f32_16x16x32_bf16 over tap pairs (conv3_halo_k32.hip: +10-12 % over the
+                // 32x32x16 form on real data, profiles/r02_notes.md); CTSI_CONV_K32=0 selects conv3_halo32m_kernel (A/B timing,
+                // and the opt-in normalise-on-load experiment, which only that kernel implements)
+                const char* k32 = getenv("CTSI_CONV_K32");
+                const char* nin = getenv("CTSI_CONV_NORM_IN");
+                if (!(k32 && !strcmp(k32, "0")) && !(nin && atoi(nin) == 1)) p->halo3 = 7;
+            }
         }
         // few output channels (network heads: 128 -> 8, 128 -> 1): halo tile 4x2x16 x 16 couts, see conv3_head.hip
         const long long padded_h = (long long)ceil_div(p->Dr, 4) * ceil_div(p->Hr, 2) * ceil_div(p->Wr, 16) * 128;
@@ -901,9 +909,9 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
-    if (p->halo3 == 5 && p->m512_w16 == 2) {
+    if ((p->halo3 == 5 || p->halo3 == 7) && p->m512_w16 == 2) {
         p->TD = 4; p->TH = 8; p->TW = 16;
-    } else if (p->halo3 == 5) {
+    } else if (p->halo3 == 5 || p->halo3 == 7) {
         p->TD = 4; p->TH = 4; p->TW = 32;
     } else if (p->halo3 == 2) {
         p->TD = p->h32_w16 == 2 ? 3 : 4; p->TH = p->h32_w16 ? 4 : 2; p->TW = p->h32_w16 ? 16 : 32;
@@ -959,6 +967,7 @@ extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
     if (!p) return 0;
     if (p->halo3 == 6)   // head kernel: 8 weight rows when cout <= 8; + 1 KB: its last DMA piece is read whole
         return (size_t)p->Cin * 27 * (p->d.cout <= 8 ? 8 : 16) * 2 + 1024;
+    if (p->halo3 == 7) return ctsi_conv3_halo_k32_weight_bytes(p->Cin, p->CoutPad);   // entries padded to whole steps
     if (p->halo3) return (size_t)p->Cin * 27 * p->CoutPad * 2;   // [chunk][27][cout_pad][32 | 16 ch] bf16
     return (size_t)p->nclass * p->CoutPad * p->Ktot * 2;
 }
@@ -996,6 +1005,7 @@ extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float*
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
     if (p->halo3 == 5) return ctsi_conv3_halo_c16_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
+    if (p->halo3 == 7) return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
     if (p->halo3 == 6) {
         hipMemsetAsync((char*)packed + ctsi_conv_plan_weight_bytes(p) - 1024, 0, 1024, (hipStream_t)stream);
         return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->d.cout <= 8 ? 8 : 16, p->Cin, p->CinW, stream);
@@ -1102,7 +1112,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         h.dshift = p->dshift;
         h.tilesD = p->tilesD; h.tilesH = p->tilesH; h.tilesW = p->tilesW; h.tps = p->tps; h.mtiles = p->mtiles;
         h.ntiles_n = p->ntiles_n;
-        h.nchunks = p->Cin / (p->halo3 == 5 ? 16 : 32);
+        h.nchunks = p->Cin / (p->halo3 == 5 || p->halo3 == 7 ? 16 : 32);
         h.Cout = p->d.cout; h.CoutPad = p->CoutPad;
         h.cout_stride = o->cout_stride; h.c_off = o->c_off;
         {   // n-major block order (one n-tile's 3.5 MB weight slab at a time per XCD instead of all of them: the 48x32x32 /
@@ -1133,6 +1143,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         if (p->halo3 == 6)
             return ctsi_conv3_head_launch(&h, p->d.cout <= 8 ? 8 : 16, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
         if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, p->m512_w16, stream);
+        if (p->halo3 == 7) return ctsi_conv3_halo_k32_launch(&h, p->m512_w16, stream);
         return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? (p->h32_w16 == 2 ? 4 : (p->h32_w16 ? 3 : 1)) : 0, stream);
     }
     CTSI_CHECK_ARG(!p->halo3, "ctsi_conv_fwd: the 3x3x3 halo-tile plan supports bf16 NDHWC output without activation");

@@ -112,4 +112,8 @@ extern "C" int ctsi_conv3_halo_c16_pack(const float* w, void* packed, int cout, 
 extern "C" int ctsi_conv3_head_launch(const Conv3HaloParams* hp, int rows, int out_mode, int act, long long sn, long long sc,
                                       long long sd, long long sh, long long sw, void* stream);
 extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile, void* stream);
+extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad);
+extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
+                                        void* stream);
+extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile, void* stream);
 

@@ -154,6 +154,49 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
 
 
+CONVT_CASES = [
+    # name, cin, cout, (n,d,h,w) of the INPUT
+    ("w32_two_chunks", 32, 128, (1, 4, 4, 32)),
+    ("ragged_batch2", 64, 64, (2, 5, 7, 21)),
+    ("w16_deep_k", 256, 128, (1, 3, 8, 16)),
+    ("cout_72_pad_16ch", 16, 72, (1, 2, 3, 9)),
+    ("cout256_two_ntiles", 48, 256, (1, 6, 5, 34)),
+]
+
+
+@pytest.mark.parametrize("tile", ["16", "32"])
+@pytest.mark.parametrize("name,cin,cout,dims", CONVT_CASES, ids=[c[0] for c in CONVT_CASES])
+def test_conv_transpose_halo_tile_kernel(G, monkeypatch, name, cin, cout, dims, tile):
+    """ConvTranspose3d (3,4,4) / (1,2,2) / pad 1 (reference models/unet3d.py:218-221, models/vae.py decoder) on the 12-entry
+    form of conv3_halo_k32_kernel: four parity classes, both tile shapes, ragged edges, batch 2, GroupNorm statistics over
+    the interleaved output; the gather kernel must agree on the same problem."""
+    n, d, h, w = dims
+    x = bf16_round(formula_input((n, cin, d, h, w), 61))
+    wt = bf16_round(_w((cin, cout, 3, 4, 4), 62, transposed=True))
+    b = formula_input((cout,), 63) * 0.1
+    ref = F.conv_transpose3d(x, wt, b, stride=(1, 2, 2), padding=(1, 1, 1))
+    groups = 8
+    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
+    monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile == "16" else "0")
+    import ctypes as C
+    import importlib
+    E = importlib.import_module("video-to-video-diffusion_amd.engine")
+    lib, plan, mode = G.ctx().lib, C.c_void_p(), C.c_int()
+    lib.conv_plan_create(C.byref(plan), C.byref(E.ConvDesc(1, 3, 4, 4, 2, 2, 1, 1, 1, n, cin, 0, cout, d, h, w, 0)))
+    lib.conv_plan_config(plan, None, None, C.byref(mode))
+    lib.conv_plan_destroy(plan)
+    assert mode.value == 9                                   # the halo-tile kernel, not the gather kernel
+    y, sums = G.run_conv(x, None, wt, b, transposed=True, k=(3, 4, 4), s=(2, 2), want_stats=True, groups=groups)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert rel_l2(y, ref) < CONV_TOL, name
+    rg = ref.reshape(n, groups, -1).double()
+    assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+    assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
+    monkeypatch.setenv("CTSI_CONV_K32T", "0")
+    y2, _ = G.run_conv(x, None, wt, b, transposed=True, k=(3, 4, 4), s=(2, 2))
+    assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
 def test_conv_fp32_strided_output_tanh_and_padded_input(G):
     # VAE decoder head: 128 -> 1 channel, tanh, written straight to fp32 NCDHW (models/vae.py:202-203)
     x = bf16_round(formula_input((1, 128, 3, 6, 5), 5))

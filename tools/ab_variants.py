@@ -12,6 +12,7 @@ ap.add_argument("variants", nargs="+")
 ap.add_argument("--cin", type=int, default=512); ap.add_argument("--cout", type=int, default=512)
 ap.add_argument("--dhw", type=int, nargs=3, default=[48, 32, 32]); ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--n", type=int, default=1); ap.add_argument("--f32", action="store_true")
+ap.add_argument("--transposed", action="store_true", help="ConvTranspose3d (3,4,4) / (1,2,2); --dhw is the INPUT grid")
 ap.add_argument("--zero", action="store_true", help="all-zero operands: cycles at the unthrottled clock (MI355X_MICROARCH.md, DVFS give-back)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -25,6 +26,8 @@ for v in a.variants:
             names.add(kv.split("=")[0])
 with ctx.scope():
     wt = torch.randn(a.cout, a.cin, 3, 3, 3, device=dev) * (0.0 if a.zero else 0.02)
+    if a.transposed:
+        wt = torch.randn(a.cin, a.cout, 3, 4, 4, device=dev) * (0.0 if a.zero else 0.02)
     b = torch.randn(a.cout, device=dev)
     for v in a.variants:
         for nme in names:
@@ -44,6 +47,8 @@ with ctx.scope():
             vox = d * h * w
             prog.conv("c", lambda: wt, lambda: b, x, None, cout=a.cout, f32_out=y,
                       f32_strides=(vox * a.cout, 1, h * w * a.cout, w * a.cout, a.cout))
+        elif a.transposed:
+            prog.conv("c", lambda: wt, lambda: b, x, None, cout=a.cout, want_stats=True, transposed=True, k=(3, 4, 4), s=(2, 2))
         else:
             prog.conv("c", lambda: wt, lambda: b, x, None, cout=a.cout, want_stats=True)
         prog.finalize_layout()

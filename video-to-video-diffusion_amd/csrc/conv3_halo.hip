@@ -581,8 +581,11 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
         const int vs2 = (kd2 * HH + kh2) * HW;
         __builtin_amdgcn_sched_barrier(0);
         H32_PHASE(fa1, fb1, fa0, fb0, hbuf2, wbuf2, vs2, 0, true);
-        if (!(p.dbg & 16)) H32_ISSUE();
+        // SIMD partners (waves w, w + 4) issue their pieces at different phase boundaries (+1.7-2.4 %, profiles/r02_notes.md):
+        // while one issues -- and feeds no MFMAs -- the other runs a phase on the matrix pipe (p.dbg & 32: all waves here)
+        if (!(p.dbg & 16) && (wave < 4 || (p.dbg & 32))) H32_ISSUE();
         H32_PHASE(fa2, fb2, fa1, fb1, hbuf2, wbuf2, vs2, 1, true);
+        if (!(p.dbg & 16) && wave >= 4 && !(p.dbg & 32)) H32_ISSUE();
         g = g2;
         cc = cc2;
     }

@@ -21,17 +21,26 @@
 #include "conv3_halo_common.h"
 #include <stdlib.h>
 
-template <int TD_, int TH_, int TW_ = 32>
+// <TD, TH, TW, BN, UPS>: tile TD x TH x TW = 512 voxels, BN couts per block, UPS units per step (one barrier per step):
+//   <4,4,32,128,2> / <4,8,16,128,2>: per wave 64 voxels x 128 couts (32 MFMAs, 12 ds_read_b128 per unit), steps of 4 entries;
+//   <4,4,32, 64,4> / <4,8,16, 64,4>: per wave 64 x 64 (16 MFMAs, 8 reads per unit), steps of 8 entries -- the same 16 KB of
+//     weights and 64 MFMAs per wave and barrier -- for levels where 128-cout blocks leave CUs idle (48 x 32 x 32 x 512 couts:
+//     96 tiles x 4 = 384 blocks = 1.5 rounds of the 256 CUs; x 8 = 768 = 3 whole rounds).  Parity-tested, then measured
+//     1.5-3 % SLOWER there than conv3_halo32_kernel's 768 blocks of 256 x 128 (1126-1159 vs 1148-1176 TFLOP/s; 0.5 LDS reads per
+//     MFMA instead of 0.375 and twice the halo DMA per FLOP eat the MFMA-shape gain): NOT instantiated or dispatched
+//     (profiles/r02_notes.md).
+template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2>
 struct HkCfg {
-    static constexpr int TD = TD_, TH = TH_, TW = TW_;
+    static constexpr int TD = TD_, TH = TH_, TW = TW_, UPS = UPS_;
     static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
     static constexpr int HV = HD * HH * HW;                 // <4,4,32>: 1224 halo voxels
     static constexpr int HALO_INSTR = (HV + 31) / 32;       // wave-DMAs of 32 voxels x 32 B
     static constexpr int HALO_BYTES = HALO_INSTR * 1024;
     static constexpr int BM = TD * TH * TW;                 // 512
-    static constexpr int BN = 128;
-    static constexpr int TAP_BYTES = BN * 32;               // 4096: [128 couts][16 channels] bf16
-    static constexpr int STEP_TAPS = 4;
+    static constexpr int BN = BN_;
+    static constexpr int NJ = BN / 16;                      // 16-cout B tiles per wave
+    static constexpr int TAP_BYTES = BN * 32;               // [BN couts][16 channels] bf16
+    static constexpr int STEP_TAPS = 2 * UPS;
     static constexpr int WSLOT_BYTES = STEP_TAPS * TAP_BYTES;   // 16384
     static constexpr int NWS = 4;                           // three steps in flight + the one being read
     static constexpr int NWAVE = BM / 64;
@@ -43,7 +52,8 @@ struct HkCfg {
     static constexpr int OFF_CS = OFF_ROW + BM * 8;
     static constexpr int LDS_BYTES = OFF_CS + NWAVE * BN * 8;
     static constexpr int LPW = 64 / TW;                     // W-lines per wave
-    static_assert(NWAVE == 8 && NPIECE <= 5 && TH % LPW == 0 && LDS_BYTES <= 160 * 1024, "unsupported tile");
+    static_assert(NWAVE == 8 && NPIECE <= 5 && TH % LPW == 0 && LDS_BYTES <= 160 * 1024 && WSLOT_BYTES == 16384 &&
+                      (UPS == 2 || UPS == 4), "unsupported tile");
     // A tile i (rows [16 i, 16 i + 16) of the wave's 64): halo-voxel offset from the wave's first voxel
     static constexpr int a_imm(int i) { return (((16 * i) / TW) * HW + (16 * i) % TW) * 32; }
 };
@@ -54,15 +64,23 @@ __device__ __forceinline__ void hk_wait_vm(int allowed) {   // wave-uniform `all
         case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
     }
 }
 
-template <int TD_, int TH_, int TW_ = 32>
+// TR = true: ConvTranspose3d k = (3,4,4), s = (1,2,2), p = 1 (models/unet3d.py:218-221 Upsample, models/vae.py decoder): output
+// voxel (d, 2 h + py, 2 w + px) of parity class (py, px) is a 3 x 2 x 2-tap convolution on the INPUT grid (k_h in {1, 3} at
+// input rows {h, h - 1} for py = 0, {2, 0} at {h, h + 1} for py = 1; same along w; i_d = o_d + 1 - k_d), i.e. the same halo
+// tile as the 3x3x3 conv with 12 entries per chunk instead of 27.  One block = one (input tile, class, n-tile); the four
+// classes of a tile are neighbours in the grid (they share the halo in L2).
+template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, 512)))
 conv3_halo_k32_kernel(const Conv3HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using Cfg = HkCfg<TD_, TH_, TW_>;
+    using Cfg = HkCfg<TD_, TH_, TW_, BN_, UPS_>;
+    constexpr int UPS = Cfg::UPS, NJ = Cfg::NJ, NJH = Cfg::NJ / 2, STEP_TAPS = Cfg::STEP_TAPS;
+    constexpr int TAPS = TR ? 12 : 27;                       // entries per 16-channel chunk
     constexpr int TH = Cfg::TH, TW = Cfg::TW, HH = Cfg::HH, HW = Cfg::HW, HV = Cfg::HV;
     constexpr int HALO_INSTR = Cfg::HALO_INSTR, HALO_BYTES = Cfg::HALO_BYTES, BM = Cfg::BM, BN = Cfg::BN;
     constexpr int TAP_BYTES = Cfg::TAP_BYTES, WSLOT_BYTES = Cfg::WSLOT_BYTES, NWS = Cfg::NWS, NWAVE = Cfg::NWAVE;
@@ -76,8 +94,17 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const int bid = xcd_remap_h(blockIdx.x, gridDim.x);
-    int mt, nt;
-    h3_decode_tile(bid, p.mtiles, p.ntiles_n, p.n_major, &mt, &nt);
+    int mt, nt, cls = 0;
+    if (TR) {
+        const int per_m = 4 * p.ntiles_n;
+        mt = bid / per_m;
+        const int rem = bid - mt * per_m;
+        cls = rem / p.ntiles_n;
+        nt = rem - cls * p.ntiles_n;
+    } else {
+        h3_decode_tile(bid, p.mtiles, p.ntiles_n, p.n_major, &mt, &nt);
+    }
+    const int py = cls >> 1, px = cls & 1;
     const int n0 = nt * BN;
     const int nb = mt / p.tps;
     int r0 = mt - nb * p.tps;
@@ -91,8 +118,12 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         const int mm = tid % TW, line = tid / TW;
         const int d = d0 + line / TH, h = h0 + line % TH, w = w0 + mm;
         long long off = -1;
-        if (d < p.Do && h < p.Ho && w < p.Wo)
+        if (TR) {
+            if (d < p.Do && 2 * h < p.Ho && 2 * w < p.Wo)
+                off = ((((long long)nb * p.Do + d) * p.Ho + 2 * h + py) * p.Wo + 2 * w + px) * p.cout_stride + p.c_off;
+        } else if (d < p.Do && h < p.Ho && w < p.Wo) {
             off = ((((long long)nb * p.Do + d) * p.Ho + h) * p.Wo + w) * p.cout_stride + p.c_off;
+        }
         s_rowoff[tid] = off;
     }
 
@@ -101,7 +132,9 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const long long basevox = ((long long)(nb * p.Di + dlo) * p.Hi) * p.Wi;
     const v4i_t rs1 = h3_make_rsrc(reinterpret_cast<const char*>(p.x1) + basevox * p.C1 * 2, 0x7fffffffu);
     const v4i_t rs2 = h3_make_rsrc(reinterpret_cast<const char*>(p.x2) + basevox * p.C2 * 2, 0x7fffffffu);
-    const v4i_t rsw = h3_make_rsrc(reinterpret_cast<const char*>(p.w) + (long long)n0 * 32, 0x7fffffffu);
+    // (TR: one packed image per class, each padded to whole steps)
+    const long long w_class = (long long)((p.nchunks * TAPS + STEP_TAPS - 1) / STEP_TAPS) * STEP_TAPS * p.CoutPad * 32;
+    const v4i_t rsw = h3_make_rsrc(reinterpret_cast<const char*>(p.w) + cls * w_class + (long long)n0 * 32, 0x7fffffffu);
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;
 
     // halo DMA: piece j = wave + NWAVE * i covers halo voxels 32 j .. 32 j + 31; lane -> voxel 32 j + lane / 2, 16-byte half lane & 1
@@ -118,8 +151,8 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     }
     const unsigned hq16 = (unsigned)((lane & 1) * 16);
     const int C1 = p.C1, C2 = p.C2, CoutPad = p.CoutPad, nchunks = p.nchunks;
-    const int Q = nchunks * 27;                              // (chunk, tap) entries
-    const int S = (Q + 3) >> 2;                              // steps of 4 entries (the packed image is zero-padded to 4 S)
+    const int Q = nchunks * TAPS;                            // (chunk, tap) entries
+    const int S = (Q + STEP_TAPS - 1) / STEP_TAPS;           // steps (the packed image is zero-padded to whole steps)
 
     auto issue_halo = [&](int cc, int i) -> int {
         const int j = wave + NWAVE * i;
@@ -143,15 +176,16 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             h3_dma16(rs1, dst, voff, soff);
         return 1;
     };
-    // weights of step s = 4 entries x 4 KB = 16 pieces of 1 KB: wave w copies pieces w and 8 + w
+    // weights of step s = STEP_TAPS entries x TAP_BYTES = 16 pieces of 1 KB: wave w copies pieces w and 8 + w
     const unsigned w_voff = (unsigned)lane * 16u;
     auto issue_weights = [&](int s) {
         const unsigned slot = lds0 + OFF_W + (s % NWS) * WSLOT_BYTES;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int piece = wave + NWAVE * k;
-            const int e = piece >> 2, quarter = piece & 3;
-            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((s * 4 + e) * CoutPad) * 32 + quarter * 1024);
+            constexpr int PPT = TAP_BYTES / 1024;            // pieces per entry
+            const int e = piece / PPT, quarter = piece % PPT;
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((s * STEP_TAPS + e) * CoutPad) * 32 + quarter * 1024);
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(slot + piece * 1024));
             h3_dma16(rsw, dst, w_voff, soff);
         }
@@ -172,23 +206,32 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     // weights are zero in the packed image; a repeated REAL tap keeps 0 x value finite wherever the real product is)
     auto tap_off = [&](int q) -> int {
         q = q < Q ? q : Q - 1;
-        const int cc = q / 27, t = q - cc * 27;
-        const int kd = t / 9, t2 = t - kd * 9;
-        const int kh = t2 / 3, kw = t2 - kh * 3;
+        const int cc = q / TAPS, t = q - cc * TAPS;
+        int kd, kh, kw;                                      // halo coordinates of the tap (0..2 each)
+        if (TR) {
+            kd = 2 - (t >> 2);
+            kh = ((t >> 1) & 1) ? (py ? 2 : 0) : 1;
+            kw = (t & 1) ? (px ? 2 : 0) : 1;
+        } else {
+            kd = t / 9;
+            const int t2 = t - kd * 9;
+            kh = t2 / 3;
+            kw = t2 - kh * 3;
+        }
         return (cc & 1) * HALO_BYTES + ((kd * HH + kh) * HW + kw) * 32;
     };
 
-    f32x4 acc[4][8];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.0f;
 
-    bf16x8 fa0[4], fa1[4], fbl[4], fbh[4];
+    bf16x8 fa0[4], fa1[4], fbl[NJH], fbh[NJH];
 
-    // A fragments i0, i0 + 1 of unit u into FA; B fragments j0 .. j0 + 3 of the unit `uu` (0 / 1) of weight slot `wslot` into FB
+    // A fragments i0, i0 + 1 of a unit into FA; B fragments j0 .. j0 + NJH - 1 of unit `uu` of the step at BADDR into FB
 #define HK_LOAD_A(FA, I0, AADDR)                                                                               \
     {                                                                                                          \
         FA[I0] = *reinterpret_cast<const bf16x8*>(smem + (AADDR) + Cfg::a_imm(I0));                            \
@@ -196,23 +239,23 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     }
 #define HK_LOAD_B(FB, J0, BADDR, UU)                                                                           \
     {                                                                                                          \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < NJH; ++j_)                                                     \
             FB[j_] = *reinterpret_cast<const bf16x8*>(smem + (BADDR) + (UU) * 2 * TAP_BYTES + ((J0) + j_) * 512); \
     }
 #define HK_MFMA(FA, FB, J0)                                                                                    \
     {                                                                                                          \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)       \
+        _Pragma("unroll") for (int j_ = 0; j_ < NJH; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)     \
             acc[i_][(J0) + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[i_], FB[j_], acc[i_][(J0) + j_], 0, 0, 0); \
     }
-    // 16 MFMAs with the phase's 6 ds_read_b128 in its first gaps (they feed the NEXT phase, 10 MFMAs = 160+ cycles later)
+    // a phase: 4 NJH MFMAs with its NJH + 2 ds_read_b128 in the first gaps (they feed the NEXT phase)
 #define HK_SCHED()                                                                                             \
     {                                                                                                          \
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                     \
-        _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < NJH + 2; ++q_) {                                               \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
         }                                                                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJH - (NJH + 2), 0);                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
 
@@ -233,70 +276,83 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    int n_prev = 0;                  // DMAs of this wave's most recent issue group (wave-uniform)
+    // ---- main loop ------------------------------------------------------------------------------------------------------------
+    // Units u = UPS s + uu.  Unit u's fragments are loaded during unit u - 1 (its second B half during its own first phase).
+    // Barrier B_s stands before the LAST unit of step s: everything step s + 1 reads has landed and is visible (the loads of
+    // step s + 1's first unit run in that last unit); every wave has drained weight slot (s - 1) % NWS and any halo chunk whose
+    // last entry lies in step s.  Issue group s (behind B_s) = weights of step s + 3 into that slot + halo pieces of the next
+    // chunk.  At B_t a wave waits for all its pieces but those of group t - 1 (counted vmcnt); when halo pieces of group t - 1
+    // are needed by step t + 1 (UPS = 4: a chunk lasts 3.4 steps), they were issued BEFORE the group's weights and only those
+    // weight pieces may stay in flight.
+    int n_prev = 0;                  // pieces of the most recent issue group that may stay in flight at the next barrier
     int hc = 1, hp = 0, hfree = 0;   // next halo chunk to fetch, its next piece, the first step whose group may issue it
+    // halo pieces per group: a chunk lasts 6.75 steps (27 entries, UPS 2: 2 + 1 + 1 + 1), 3.4 (UPS 4) or 3 (TR: 12 entries): 3 + 2
+    constexpr int H_FIRST = (UPS == 2 && !TR) ? 2 : 3, H_LATER = (UPS == 2 && !TR) ? 1 : 3;
     auto issue_group = [&](int s) {
-        int issued = 0;
-        if (s + NWS - 1 < S && !(p.dbg & 2)) {
-            issue_weights(s + NWS - 1);
-            issued += 2;
-        }
+        int n_halo = 0, n_w = 0;
+        bool urgent = false;
         if (hc < nchunks && s >= hfree && !(p.dbg & 1)) {
-            issued += issue_halo(hc, hp);
-            ++hp;
-            if (hp == 1 && NPIECE > 1) {                 // two pieces in a chunk's first group: 5 pieces fit 4 groups
-                issued += issue_halo(hc, hp);
-                ++hp;
-            }
+            // the chunk's first entry TAPS hc lies in unit (TAPS hc) >> 1 = step S': it is first read behind B_{S' - 1}
+            urgent = s + 2 >= ((TAPS * hc) >> 1) / UPS;
+            const int cnt = hp == 0 ? H_FIRST : H_LATER;
+#pragma unroll
+            for (int k = 0; k < (H_FIRST > H_LATER ? H_FIRST : H_LATER); ++k)
+                if (k < cnt && hp < NPIECE) {
+                    n_halo += issue_halo(hc, hp);
+                    ++hp;
+                }
             if (hp >= NPIECE) {
                 hp = 0;
-                hfree = (27 * hc - 1) >> 2;              // step of the unit that holds chunk hc - 1's last entry
+                hfree = ((TAPS * hc - 1) >> 1) / UPS;        // step of the unit that holds chunk hc - 1's last entry
                 ++hc;
             }
         }
-        n_prev = issued;
+        if (s + NWS - 1 < S && !(p.dbg & 2)) {
+            issue_weights(s + NWS - 1);
+            n_w = 2;
+        }
+        n_prev = urgent ? n_w : n_w + n_halo;
         __builtin_amdgcn_sched_barrier(0);
     };
+    // one unit: FAc = this unit's A fragments (fbl holds its first B half), FAn receives the next unit's
+#define HK_UNIT(FAc, FAn, BADDR, UU, BADDR_N, UU_N, AADDR_N, MID)                                              \
+    {                                                                                                          \
+        HK_LOAD_B(fbh, NJH, BADDR, UU);                                                                        \
+        HK_LOAD_A(FAn, 0, AADDR_N);                                                                            \
+        HK_MFMA(FAc, fbl, 0);                                                                                  \
+        HK_SCHED();                                                                                            \
+        MID;                                                                                                   \
+        HK_LOAD_A(FAn, 2, AADDR_N);                                                                            \
+        HK_LOAD_B(fbl, 0, BADDR_N, UU_N);                                                                      \
+        HK_MFMA(FAc, fbh, NJH);                                                                                \
+        HK_SCHED();                                                                                            \
+    }
     for (int s = 0; s < S; ++s) {
         const int baddr = b_lane + (s % NWS) * WSLOT_BYTES;
         const int baddr_n = b_lane + ((s + 1) % NWS) * WSLOT_BYTES;
-        int aaddr1, aaddr2;
-        {
-            const int oa = tap_off(4 * s + 2), ob = tap_off(4 * s + 3);
-            aaddr1 = a_lane + (tap1 ? ob : oa);              // unit 2 s + 1
-            const int oc = tap_off(4 * s + 4), od = tap_off(4 * s + 5);
-            aaddr2 = a_lane + (tap1 ? od : oc);              // unit 2 s + 2 (next step; the last step re-reads in-bounds data)
+        const int q0 = STEP_TAPS * s;
+        int an[UPS];                                             // A address of units UPS s + 1 .. UPS s + UPS (the next step's first)
+#pragma unroll
+        for (int k = 0; k < UPS; ++k) {
+            const int oa = tap_off(q0 + 2 * k + 2), ob = tap_off(q0 + 2 * k + 3);
+            an[k] = a_lane + (tap1 ? ob : oa);
         }
-        // ---- unit 2 s ----
-        HK_LOAD_B(fbh, 4, baddr, 0);
-        HK_LOAD_A(fa1, 0, aaddr1);
-        HK_MFMA(fa0, fbl, 0);
-        HK_SCHED();
-        HK_LOAD_A(fa1, 2, aaddr1);
-        HK_LOAD_B(fbl, 0, baddr, 1);
-        HK_MFMA(fa0, fbh, 4);
-        HK_SCHED();
-        // ---- barrier B_s: everything step s + 1 reads has landed (issued two groups ago or earlier) and is visible; every wave
-        //      has drained its reads of weight slot (s - 1) % NWS and of a halo chunk whose last entry lies in a unit <= 2 s + 1
+        HK_UNIT(fa0, fa1, baddr, 0, baddr, 1, an[0], );
+        if constexpr (UPS == 4) {
+            HK_UNIT(fa1, fa0, baddr, 1, baddr, 2, an[1], );
+            HK_UNIT(fa0, fa1, baddr, 2, baddr, 3, an[2], );
+        }
         hk_wait_vm(n_prev);
         if (!(p.dbg & 64)) __builtin_amdgcn_s_barrier();      // (64: timing-only ablation)
         __builtin_amdgcn_sched_barrier(0);
-        // ---- unit 2 s + 1 ----
-        HK_LOAD_B(fbh, 4, baddr, 1);
-        HK_LOAD_A(fa0, 0, aaddr2);
-        HK_MFMA(fa1, fbl, 0);
-        HK_SCHED();
-        // issue group of step s (LDS-DMA pieces: weights of step s + 3, halo pieces of the next chunk).  SIMD partners (waves w
-        // and w + 4) issue at DIFFERENT phase boundaries: a piece costs its wave ~60-100 issue cycles during which it feeds no
-        // MFMAs, so waves 0-3 issue behind the first MFMA phase after the barrier -- while waves 4-7 run their second phase on
-        // the matrix pipe -- and waves 4-7 behind that second phase (p.dbg & 16: all waves at the first boundary, for A/B timing)
-        if (wave < 4 || (p.dbg & 16)) issue_group(s);
-        HK_LOAD_A(fa0, 2, aaddr2);
-        HK_LOAD_B(fbl, 0, baddr_n, 0);
-        HK_MFMA(fa1, fbh, 4);
-        HK_SCHED();
+        // SIMD partners (waves w and w + 4) issue their pieces at DIFFERENT phase boundaries: a piece costs its wave ~60-100 issue
+        // cycles during which it feeds no MFMAs, so waves 0-3 issue behind the first MFMA phase after the barrier -- while waves
+        // 4-7 run their second phase on the matrix pipe -- and waves 4-7 behind that second phase (p.dbg & 16: all waves at the
+        // first boundary, for A/B timing: 5-6 % slower on real data, 12-14 % on zeros)
+        HK_UNIT(fa1, fa0, baddr, UPS - 1, baddr_n, 0, an[UPS - 1], if (wave < 4 || (p.dbg & 16)) issue_group(s));
         if (wave >= 4 && !(p.dbg & 16)) issue_group(s);
     }
+#undef HK_UNIT
 #undef HK_LOAD_A
 #undef HK_LOAD_B
 #undef HK_MFMA
@@ -315,7 +371,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) vbits |= (unsigned)(s_rowoff[wave * 64 + 16 * i + 4 * kg + q] >= 0) << (4 * i + q);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int col = j * 16 + r16;
         const int co = n0 + col;
         const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
@@ -353,9 +409,10 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             t1 += s_cs[(q * BN + tid) * 2 + 0];
             t2 += s_cs[(q * BN + tid) * 2 + 1];
         }
-        const long long slab = (long long)p.mtiles * CoutPad;
-        p.colsum[(long long)mt * CoutPad + n0 + tid] = t1;
-        p.colsum[slab + (long long)mt * CoutPad + n0 + tid] = t2;
+        const long long slab = (long long)(TR ? 4 : 1) * p.mtiles * CoutPad;   // [class][m-tile][cout_pad], as the gather kernel's
+        const long long tg = (long long)cls * p.mtiles + mt;
+        p.colsum[tg * CoutPad + n0 + tid] = t1;
+        p.colsum[slab + tg * CoutPad + n0 + tid] = t2;
     }
     {
         constexpr int CPR = BN / 8;
@@ -373,59 +430,84 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-// ---- weight packing: fp32 (cout, cin, 3,3,3) -> bf16 [entry q = chunk16 * 27 + tap][cout_pad][16], zero entries up to 4 S ----
+// ---- weight packing: fp32 (cout, cin, 3,3,3) -> bf16 [entry q = chunk16 * 27 + tap][cout_pad][16], zero entries up to whole steps;
+//      ConvTranspose3d (cin, cout, 3,4,4) -> [class][entry q = chunk16 * 12 + t][cout_pad][16], t = (a * 2 + b) * 2 + c with
+//      kernel taps k_d = a, k_h = (py ? {2, 0} : {1, 3})[b], k_w likewise (the tap order conv3_halo_k32_kernel<TR> walks)
 __global__ void conv3_halo_k32_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int CoutPad,
-                                           int CinW, int nchunks, long long total) {
-    const int Q = nchunks * 27;
+                                           int CinW, int nchunks, long long per_class, int transposed) {
+    const int taps = transposed ? 12 : 27;
+    const int Q = nchunks * taps;
+    const long long total = per_class * (transposed ? 4 : 1);
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx & 15);
-        const long long row = idx >> 4;                // q * CoutPad + cout
+        const int cls = (int)(idx / per_class);
+        const long long in_class = idx - cls * per_class;
+        const int e = (int)(in_class & 15);
+        const long long row = in_class >> 4;           // q * CoutPad + cout
         const int co = (int)(row % CoutPad);
         const long long q = row / CoutPad;
         float v = 0.0f;
         if (q < Q) {
-            const int tap = (int)(q % 27), cc = (int)(q / 27);
+            const int t = (int)(q % taps), cc = (int)(q / taps);
             const int ci = cc * 16 + e;
-            if (co < Cout && ci < CinW) v = w[((long long)co * CinW + ci) * 27 + tap];
+            if (co < Cout && ci < CinW) {
+                if (transposed) {
+                    const int py = cls >> 1, px = cls & 1;
+                    const int a = t >> 2, b = (t >> 1) & 1, c = t & 1;
+                    const int ky = py ? (b ? 0 : 2) : (b ? 3 : 1), kx = px ? (c ? 0 : 2) : (c ? 3 : 1);
+                    v = w[((long long)ci * Cout + co) * 48 + (a * 4 + ky) * 4 + kx];
+                } else {
+                    v = w[((long long)co * CinW + ci) * 27 + t];
+                }
+            }
         }
         out[idx] = f32_to_bf16(v);
     }
 }
 
-extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad) {
-    const long long q = (long long)(cin / 16) * 27;
-    return (size_t)(((q + 3) / 4) * 4 * cout_pad * 32);
+extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad, int bn, int transposed) {
+    const long long q = (long long)(cin / 16) * (transposed ? 12 : 27), step = bn == 64 ? 8 : 4;   // entries per step: 2 x UPS
+    return (size_t)(((q + step - 1) / step) * step * cout_pad * 32) * (transposed ? 4 : 1);
 }
 
-extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
-                                        void* stream) {
-    CTSI_CHECK_ARG(w && packed && cin % 16 == 0 && cout_pad % 128 == 0, "ctsi_conv3_halo_k32_pack: bad arguments");
+extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w, int bn,
+                                        int transposed, void* stream) {
+    CTSI_CHECK_ARG(w && packed && cin % 16 == 0 && (bn == 64 || bn == 128) && cout_pad % bn == 0 && (!transposed || cin_w == cin),
+                   "ctsi_conv3_halo_k32_pack: bad arguments");
     const int nchunks = cin / 16;
-    const long long total = (long long)ctsi_conv3_halo_k32_weight_bytes(cin, cout_pad) / 2;
+    const long long total = (long long)ctsi_conv3_halo_k32_weight_bytes(cin, cout_pad, bn, transposed) / 2;
+    const long long per_class = transposed ? total / 4 : total;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(conv3_halo_k32_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed,
-                       cout, cout_pad, cin_w, nchunks, total);
+                       cout, cout_pad, cin_w, nchunks, per_class, transposed);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }
 
-extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16 */, void* stream) {
-    using C44 = HkCfg<4, 4>;
-    using C48 = HkCfg<4, 8, 16>;
-    auto k44 = conv3_halo_k32_kernel<4, 4, 32>;
-    auto k48 = conv3_halo_k32_kernel<4, 8, 16>;
+template <int TD, int TH, int TW, int BN, int UPS, bool TR>
+static void hk_launch(const Conv3HaloParams* hp, hipStream_t stream) {
+    using Cfg = HkCfg<TD, TH, TW, BN, UPS>;
+    auto k = conv3_halo_k32_kernel<TD, TH, TW, BN, UPS, TR>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)k44, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)k48, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const int grid = hp->mtiles * hp->ntiles_n;
-    if (tile == 2)
-        hipLaunchKernelGGL(k48, dim3(grid), dim3(C48::NTH), C48::LDS_BYTES, (hipStream_t)stream, *hp);
-    else
-        hipLaunchKernelGGL(k44, dim3(grid), dim3(C44::NTH), C44::LDS_BYTES, (hipStream_t)stream, *hp);
+    hipLaunchKernelGGL(k, dim3((TR ? 4 : 1) * hp->mtiles * hp->ntiles_n), dim3(Cfg::NTH), Cfg::LDS_BYTES, stream, *hp);
+}
+
+extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16 */, int bn, void* stream) {
+    CTSI_CHECK_ARG(bn == 128, "ctsi_conv3_halo_k32_launch: bad BN %d", bn);
+    if (hp->tr) {
+        if (tile == 2)
+            hk_launch<4, 8, 16, 128, 2, true>(hp, (hipStream_t)stream);
+        else
+            hk_launch<4, 4, 32, 128, 2, true>(hp, (hipStream_t)stream);
+    } else if (tile == 2) {
+        hk_launch<4, 8, 16, 128, 2, false>(hp, (hipStream_t)stream);
+    } else {
+        hk_launch<4, 4, 32, 128, 2, false>(hp, (hipStream_t)stream);
+    }
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

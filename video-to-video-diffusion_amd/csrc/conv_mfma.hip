@@ -898,6 +898,27 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 if (!(k32 && !strcmp(k32, "0")) && !(nin && atoi(nin) == 1)) p->halo3 = 7;
             }
         }
+        // ConvTranspose3d (3,4,4) / (1,2,2) on the k32 kernel: each parity class is a 12-tap convolution on the input grid with
+        // the 3x3x3 conv's halo tile (conv3_halo_k32.hip, TR = true); CTSI_CONV_K32T=0 keeps the gather kernel (A/B timing)
+        if (d.transposed && d.c2 == 0 && d.c1 % 16 == 0 && d.cout >= 64 && d.cout % 8 == 0 && p->CinW == p->Cin &&
+            extent < 2.0e9) {
+            auto useful = [&](int td, int th, int tw) {
+                const long long t = (long long)ceil_div(p->Dr, td) * ceil_div(p->Hr, th) * ceil_div(p->Wr, tw);
+                return (double)rows / ((double)t * td * th * tw);
+            };
+            const double u32 = useful(4, 4, 32), u16 = useful(4, 8, 16);
+            const char* kt = getenv("CTSI_CONV_K32T");
+            const bool force = getenv("CTSI_CONV_FORCE_HALO3") != nullptr;
+            if ((u32 >= 0.7 || u16 >= 0.7 || force) && !(kt && !strcmp(kt, "0")) && !getenv("CTSI_CONV_NO_HALO3")) {
+                p->halo3 = 7;
+                p->BM = 512;
+                p->BN = 128;
+                p->m512_w16 = u16 > u32 ? 2 : 0;
+                const char* w16 = getenv("CTSI_CONV_M512W16");    // "0" | "1" (tuning / test aid)
+                if (w16 && !strcmp(w16, "1")) p->m512_w16 = 2;
+                if (w16 && !strcmp(w16, "0")) p->m512_w16 = 0;
+            }
+        }
         // few output channels (network heads: 128 -> 8, 128 -> 1): halo tile 4x2x16 x 16 couts, see conv3_head.hip
         const long long padded_h = (long long)ceil_div(p->Dr, 4) * ceil_div(p->Hr, 2) * ceil_div(p->Wr, 16) * 128;
         if (!p->halo3 && k3 && !p->small && d.c2 == 0 && d.c1 % 32 == 0 && d.cout <= 16 && (rows * 10 >= padded_h * 7 || getenv("CTSI_CONV_FORCE_HALO3")) &&
@@ -967,7 +988,7 @@ extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
     if (!p) return 0;
     if (p->halo3 == 6)   // head kernel: 8 weight rows when cout <= 8; + 1 KB: its last DMA piece is read whole
         return (size_t)p->Cin * 27 * (p->d.cout <= 8 ? 8 : 16) * 2 + 1024;
-    if (p->halo3 == 7) return ctsi_conv3_halo_k32_weight_bytes(p->Cin, p->CoutPad);   // entries padded to whole steps
+    if (p->halo3 == 7) return ctsi_conv3_halo_k32_weight_bytes(p->Cin, p->CoutPad, p->BN, p->d.transposed);   // entries padded to whole steps
     if (p->halo3) return (size_t)p->Cin * 27 * p->CoutPad * 2;   // [chunk][27][cout_pad][32 | 16 ch] bf16
     return (size_t)p->nclass * p->CoutPad * p->Ktot * 2;
 }
@@ -1005,7 +1026,8 @@ extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float*
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
     if (p->halo3 == 5) return ctsi_conv3_halo_c16_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
-    if (p->halo3 == 7) return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
+    if (p->halo3 == 7)
+        return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, p->BN, p->d.transposed, stream);
     if (p->halo3 == 6) {
         hipMemsetAsync((char*)packed + ctsi_conv_plan_weight_bytes(p) - 1024, 0, 1024, (hipStream_t)stream);
         return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->d.cout <= 8 ? 8 : 16, p->Cin, p->CinW, stream);
@@ -1143,7 +1165,8 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         if (p->halo3 == 6)
             return ctsi_conv3_head_launch(&h, p->d.cout <= 8 ? 8 : 16, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
         if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, p->m512_w16, stream);
-        if (p->halo3 == 7) return ctsi_conv3_halo_k32_launch(&h, p->m512_w16, stream);
+        h.tr = p->d.transposed;
+        if (p->halo3 == 7) return ctsi_conv3_halo_k32_launch(&h, p->m512_w16, p->BN, stream);
         return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? (p->h32_w16 == 2 ? 4 : (p->h32_w16 ? 3 : 1)) : 0, stream);
     }
     CTSI_CHECK_ARG(!p->halo3, "ctsi_conv_fwd: the 3x3x3 halo-tile plan supports bf16 NDHWC output without activation");

@@ -102,6 +102,7 @@ struct Conv3HaloParams {
     int nin_pad_lo, nin_pad_hi;   // depth-sharded input: the first / last halo slice is a volume end (reads as zero padding)
     float nin_eps;
     double nin_count;
+    int tr;               // conv3_halo_k32_kernel: ConvTranspose3d (3,4,4) / (1,2,2): Do/Ho/Wo are the OUTPUT dims, tiles walk the input grid
 };
 
 extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
@@ -112,8 +113,8 @@ extern "C" int ctsi_conv3_halo_c16_pack(const float* w, void* packed, int cout, 
 extern "C" int ctsi_conv3_head_launch(const Conv3HaloParams* hp, int rows, int out_mode, int act, long long sn, long long sc,
                                       long long sd, long long sh, long long sw, void* stream);
 extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile, void* stream);
-extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad);
-extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
-                                        void* stream);
-extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile, void* stream);
+extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad, int bn, int transposed);
+extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w, int bn,
+                                        int transposed, void* stream);
+extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile, int bn, void* stream);
 

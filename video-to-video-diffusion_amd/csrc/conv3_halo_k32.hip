@@ -96,11 +96,18 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const int bid = xcd_remap_h(blockIdx.x, gridDim.x);
     int mt, nt, cls = 0;
     if (TR) {
-        const int per_m = 4 * p.ntiles_n;
-        mt = bid / per_m;
-        const int rem = bid - mt * per_m;
-        cls = rem / p.ntiles_n;
-        nt = rem - cls * p.ntiles_n;
+        // siblings = the 4 ntiles_n (class, n-tile) blocks of one input tile: they share the halo, each streams its own weight
+        // slab.  G = p.n_major siblings of a tile are neighbours in the grid (0: all of them), the sibling groups are walked
+        // one after the other: G trades halo re-reads (x siblings / G) against the weight slabs an XCD's L2 holds at a time.
+        const int ns = 4 * p.ntiles_n;
+        const int G = (p.n_major > 0 && p.n_major < ns && ns % p.n_major == 0) ? p.n_major : ns;
+        const int per_g = p.mtiles * G;
+        const int sg = bid / per_g;
+        const int rem = bid - sg * per_g;
+        mt = rem / G;
+        const int sib = sg * G + (rem - mt * G);
+        cls = sib / p.ntiles_n;
+        nt = sib - cls * p.ntiles_n;
     } else {
         h3_decode_tile(bid, p.mtiles, p.ntiles_n, p.n_major, &mt, &nt);
     }

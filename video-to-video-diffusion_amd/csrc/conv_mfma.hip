@@ -1142,6 +1142,9 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             // thrash the 4 MB L2).  Interleaved timing shows no speed difference (1214 vs 1211 TFLOP/s), so it stays opt-in.
             const char* nm = getenv("CTSI_CONV_NMAJOR");   // "1" (tuning aid; read per launch)
             h.n_major = nm ? atoi(nm) : 0;
+            // (ConvTranspose on the k32 kernel: number of sibling (class, n-tile) blocks of an input tile kept adjacent;
+            //  4 = one group's weight slabs fit an XCD's L2: +0.5-1 % over all 8 / 16 siblings adjacent)
+            if (p->d.transposed && !nm) h.n_major = 4;
         }
         {
             const char* dbgf = getenv("CTSI_DEBUG_FLAGS");      // (read per launch: tools/ab_variants.py alternates them)

@@ -482,7 +482,7 @@ class Program:
                 co.nin_sums = prog._gn_sums.data_ptr() + nin_slot * 8
             lib.conv_fwd(plan, x1p, x2p, _ptr(holder[0]), bp, C.byref(co), sptr)
 
-        kernel = "conv_mfma_%dx%d_m%d" % (bm.value, bn.value, mode.value)
+        kernel = "conv_mfma_%dx%d_m%d%s" % (bm.value, bn.value, mode.value, "t" if (transposed and mode.value == 9) else "")
         if norm_in is not None:
             name = name + "+gn_in"
         self._emit(run, name, fl, kernel)

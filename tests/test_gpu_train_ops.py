@@ -114,6 +114,69 @@ def test_wgrad_and_dgrad_vs_autograd(G, name, cin, cout, dims, kind):
     assert e_w <= 3e-3 and e_x <= 3e-3
 
 
+S1_CASES = [
+    # name, cin, cout, (n,d,h,w), k
+    ("k3_128_128", 128, 128, (1, 4, 6, 6), 3),
+    ("k3_batch2_odd_64_192", 64, 192, (2, 3, 7, 9), 3),
+    ("k3_cin16_stem", 16, 128, (2, 4, 5, 6), 3),
+    ("k3_long_k_256_128", 256, 128, (1, 6, 20, 24), 3),       # several split-K slices, W rows that straddle K-steps
+    ("k1_256_64", 256, 64, (1, 2, 6, 6), 1),
+]
+
+
+@pytest.mark.parametrize("bk", ["32", "64"])
+@pytest.mark.parametrize("name,cin,cout,dims,k", S1_CASES, ids=[c[0] for c in S1_CASES])
+def test_wgrad_tap_sharing_kernel(G, monkeypatch, name, cin, cout, dims, k, bk):
+    """conv_wgrad_s1_kernel<TG, BK> (one R slab + one halo'd G slab serve the 3 kw taps of a (kd, kh) row; K-steps of 32 or 64
+    voxels) against autograd, and run-to-run bit-identical."""
+    n, d, h, w = dims
+    x = bf16_round(formula_input((n, cin, d, h, w), 1)).requires_grad_(True)
+    kk, pp = (k, k, k), (k // 2, k // 2, k // 2)
+    wt = bf16_round(_w((cout, cin, k, k, k), 2, cin * k ** 3)).requires_grad_(True)
+    y = F.conv3d(x, wt, None, padding=k // 2)
+    dy = bf16_round(formula_input(tuple(y.shape), 3))
+    y.backward(dy)
+    T = k ** 3
+    monkeypatch.setenv("CTSI_WGRAD_S1", bk)
+    dw = _wgrad(G, dy, x.detach(), kk, (1, 1), pp, T, tuple(wt.shape), (cin * T, T, 1))
+    assert rel_l2(dw.cpu(), wt.grad) <= 3e-3, name
+    dw2 = _wgrad(G, dy, x.detach(), kk, (1, 1), pp, T, tuple(wt.shape), (cin * T, T, 1))
+    assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("name,cin,cout,dims,kind", WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_wgrad_mfma_16x16x32_form(G, monkeypatch, name, cin, cout, dims, kind):
+    """conv_wgrad_kernel<SHAPE16>: the one-tap-per-block kernel on v_mfma_f32_16x16x32_bf16 -- every layer kind, against
+    the 32x32x16 form (same products, another summation tree: fp32 rounding only) and autograd."""
+    n, d, h, w = dims
+    x = bf16_round(formula_input((n, cin, d, h, w), 1)).requires_grad_(True)
+    if kind in ("k3", "k1"):
+        kk = 3 if kind == "k3" else 1
+        k, s, p = (kk, kk, kk), (1, 1), (kk // 2, kk // 2, kk // 2)
+        wt = bf16_round(_w((cout, cin, kk, kk, kk), 2, cin * kk ** 3)).requires_grad_(True)
+        y = F.conv3d(x, wt, None, padding=kk // 2)
+    elif kind == "down":
+        k, s, p = (3, 4, 4), (2, 2), (1, 1, 1)
+        wt = bf16_round(_w((cout, cin, 3, 4, 4), 2, cin * 48)).requires_grad_(True)
+        y = F.conv3d(x, wt, None, stride=(1, 2, 2), padding=1)
+    else:
+        k, s, p = (3, 4, 4), (2, 2), (1, 1, 1)
+        wt = bf16_round(_w((cin, cout, 3, 4, 4), 2, cin * 12)).requires_grad_(True)
+        y = F.conv_transpose3d(x, wt, None, stride=(1, 2, 2), padding=1)
+    dy = bf16_round(formula_input(tuple(y.shape), 3))
+    y.backward(dy)
+    T = k[0] * k[1] * k[2]
+    res = []
+    for shape16 in ("0", "1"):
+        monkeypatch.setenv("CTSI_WGRAD_SHAPE16", shape16)
+        if kind == "up":
+            res.append(_wgrad(G, x.detach(), dy, k, s, p, T, tuple(wt.shape), (cout * T, T, 1)))
+        else:
+            res.append(_wgrad(G, dy, x.detach(), k, s, p, T, tuple(wt.shape), (cin * T, T, 1)))
+    assert rel_l2(res[1].cpu(), wt.grad) <= 3e-3, name
+    assert rel_l2(res[1].cpu(), res[0].cpu()) <= 1e-5
+
+
 def test_wgrad_two_sources_and_split_k(G):
     """A concatenated input is two calls that write disjoint input-channel slices of one weight gradient; a long
     voxel range exercises several split-K slices (fixed summation order: two runs are bit-identical)."""

@@ -54,6 +54,11 @@ __device__ __forceinline__ s16x4 wg_tr_read(unsigned lds_addr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(unsigned long long)lds_addr);
 }
 
+// SHAPE16 = true: the same tile on v_mfma_f32_16x16x32_bf16 (4 x 4 tiles of 16 x 16 per wave, one MFMA K = the whole 32-voxel
+// K-step): the operand fragments are the same transposed reads (a 16-lane group = 4 voxels x 16 channels), addressed per
+// k-group lane >> 4 instead of per k-half lane >> 5; same LDS bytes per MFMA FLOP.  (The chip holds a higher clock on this
+// shape under load: MI355X_MICROARCH.md, DVFS give-back item 7.)
+template <bool SHAPE16>
 __global__ void __launch_bounds__(256)
 conv_wgrad_kernel(const WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -129,27 +134,37 @@ conv_wgrad_kernel(const WgradParams p) {
     // 16-byte chunk 4*ct + 2*((lane>>4)&1) + (p>>1) (p = lane&3), + 8*(p&1) bytes.
     const int wr = wv >> 1, wgc = wv & 1;
     const int q = (lane & 15) >> 2, pp = lane & 3;
-    unsigned a_off[2][2], b_off[2][2];
+    constexpr int NT = SHAPE16 ? 4 : 2;                      // operand tiles per wave and side
+    unsigned a_off[NT][2], b_off[NT][2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int row = 8 * (lane >> 5) + 4 * e + q;
+        // 32x32x16: rows 8 (lane >> 5) + 4 e + q of a 16-row sub-step, channel half (lane >> 4) & 1 of the 32-channel tile;
+        // 16x16x32: rows 8 (lane >> 4) + 4 e + q of the 32-row step, the tile's 16 channels
+        const int row = SHAPE16 ? 8 * (lane >> 4) + 4 * e + q : 8 * (lane >> 5) + 4 * e + q;
         const int f = ((row & 3) << 2) | ((row >> 2) & 3);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int cha = 4 * (2 * wr + i) + 2 * ((lane >> 4) & 1) + (pp >> 1);
-            const int chb = 4 * (2 * wgc + i) + 2 * ((lane >> 4) & 1) + (pp >> 1);
+        for (int i = 0; i < NT; ++i) {
+            const int cha = SHAPE16 ? 2 * (4 * wr + i) + (pp >> 1) : 4 * (2 * wr + i) + 2 * ((lane >> 4) & 1) + (pp >> 1);
+            const int chb = SHAPE16 ? 2 * (4 * wgc + i) + (pp >> 1) : 4 * (2 * wgc + i) + 2 * ((lane >> 4) & 1) + (pp >> 1);
             a_off[i][e] = (unsigned)(256 * row + 16 * (cha ^ f) + 8 * (pp & 1));
             b_off[i][e] = (unsigned)(SLAB + 256 * row + 16 * (chb ^ f) + 8 * (pp & 1));
         }
     }
 
     f32x16 acc[2][2];
+    f32x4 acc16[4][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.0f;
 
     if (k_begin < k_end) {
         issue(k_begin, 0);
@@ -159,6 +174,23 @@ conv_wgrad_kernel(const WgradParams p) {
             const int stage = (ks - k_begin) & 1;
             if (ks + 1 < k_end) issue(ks + 1, stage ^ 1);
             const unsigned sb = lds0 + stage * STAGE;
+            if (SHAPE16) {
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const s16x4 a0 = wg_tr_read(sb + a_off[i][0]);
+                    const s16x4 a1 = wg_tr_read(sb + a_off[i][1]);
+                    const s16x4 b0 = wg_tr_read(sb + b_off[i][0]);
+                    const s16x4 b1 = wg_tr_read(sb + b_off[i][1]);
+                    af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bfr[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc16[i][j], 0, 0, 0);
+            } else
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const unsigned so = sb + sub * (16 * 256);   // rows 16*sub ...: the swizzle only sees row % 16
@@ -186,6 +218,20 @@ conv_wgrad_kernel(const WgradParams p) {
     // ---- partial tile -> workspace [slice][tap][CRpad][CGpad] ------------------------------------------------
     const int CRp = p.tiles_r * BR, CGp = p.tiles_g * BG;
     float* dst = p.part + ((size_t)sl * p.T + t) * (size_t)CRp * CGp;
+    if (SHAPE16) {   // accumulator (i, j)[r]: R channel 64 wr + 16 i + 4 (lane >> 4) + r, G channel 64 wgc + 16 j + (lane & 15)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cg = tg * BG + 64 * wgc + 16 * j + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cr = tr * BR + 64 * wr + 16 * i + 4 * (lane >> 4) + r;
+                    dst[(size_t)cr * CGp + cg] = acc16[i][j][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -210,24 +256,38 @@ conv_wgrad_kernel(const WgradParams p) {
 // ballot per tap and K-step yields the masks (skipped when all 32 voxels are valid).
 // Block = 8 waves (2 along R x 4 along G), tile 128 x 128 x TG taps, 96 accumulators per lane for TG = 3.
 namespace wg3 {
-constexpr int BR = 128, BG = 128, BK = 32, NTH = 512;
-constexpr int RSLAB = BK * 256;          // 8 KB
-constexpr int GROWS = 36;                // 32 + up to 3 halo rows, rounded to whole 4-row DMA groups
-constexpr int GSLAB = GROWS * 256;       // 9 KB
-constexpr int STAGE = RSLAB + GSLAB;
-constexpr int NS = 4;                    // LDS stages: the DMA of step s+3 is issued while step s is on the matrix cores
-constexpr int LDS_BYTES = NS * STAGE;
+constexpr int BR = 128, BG = 128, NTH = 512;
+// <BK> voxels per K-step: 32 (4 LDS stages of 17 KB, one barrier per 12 MFMAs and wave) or 64 (3 stages of 33 KB, one barrier
+// per 24 MFMAs: the step length of the forward halo-tile kernels)
+template <int BK_>
+struct Cfg {
+    static constexpr int BK = BK_;
+    static constexpr int RSLAB = BK * 256;           // [BK voxels][128 ch] bf16
+    static constexpr int GROWS = BK + 4;             // + up to 3 halo rows, rounded to whole 4-row DMA groups
+    static constexpr int GSLAB = GROWS * 256;
+    static constexpr int STAGE = RSLAB + GSLAB;
+    static constexpr int NS = BK == 64 ? 3 : 4;      // LDS stages: the DMA of step s + NS - 1 is issued while step s is on the matrix cores
+    static constexpr int LDS_BYTES = NS * STAGE;
+    static constexpr int GPW = BK / 32;              // 4-row DMA groups per wave, slab and step (8 waves x GPW x 4 rows = BK)
+    static_assert((BK == 32 || BK == 64) && LDS_BYTES <= 160 * 1024, "unsupported K-step");
+};
 }  // namespace wg3
 
 __device__ __forceinline__ unsigned wg_pair_mask(unsigned b2) {   // 2 validity bits -> dword mask over 2 bf16
     return ((b2 & 1u) ? 0x0000ffffu : 0u) | ((b2 & 2u) ? 0xffff0000u : 0u);
 }
 
-template <int TG>
+template <int N>
+__device__ __forceinline__ void wg_wait_vm() {   // all but the wave's N youngest LDS-DMA pieces landed, all LDS reads returned
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+template <int TG, int BK>
 __global__ void __launch_bounds__(512)
 conv_wgrad_s1_kernel(const WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using namespace wg3;
+    using C3 = wg3::Cfg<BK>;
+    constexpr int BR = wg3::BR, BG = wg3::BG, RSLAB = C3::RSLAB, STAGE = C3::STAGE, NS = C3::NS, GPW = C3::GPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;
     const int tid = threadIdx.x;
@@ -253,8 +313,9 @@ conv_wgrad_s1_kernel(const WgradParams p) {
     const v4i_t rsR = h3_make_rsrc(p.R, p.r_bytes);
     const v4i_t rsG = h3_make_rsrc(p.G, p.g_bytes);
 
-    // ---- staging: 8 (R) + 9 (G) wave-DMAs of 4 rows each per K-step; wave w issues R group w, G group w, and wave 0
-    //      also G group 8 --------------------------------------------------------------------------------------------
+    // ---- staging: BK/4 (R) + BK/4 + 1 (G) wave-DMAs of 4 rows each per K-step; wave w issues R and G groups w (+ 8), and
+    //      wave 0 also the G halo group (rows BK .. BK + 3).  The row swizzle only sees row % 16, so a wave's groups share
+    //      their column offsets ------------------------------------------------------------------------------------------
     const int lrow = lane >> 4, slot = lane & 15;
     auto row_col = [&](int row, int tile, int cmax, bool& ok) -> unsigned {
         const int f = ((row & 3) << 2) | ((row >> 2) & 3);
@@ -266,26 +327,30 @@ conv_wgrad_s1_kernel(const WgradParams p) {
     bool r_ok, g_ok0, g_ok1;
     const unsigned r_col = row_col(4 * wv + lrow, tr, p.CR, r_ok);
     const unsigned g_col0 = row_col(4 * wv + lrow, tg, p.CG, g_ok0);
-    const unsigned g_col1 = row_col(32 + lrow, tg, p.CG, g_ok1);
+    const unsigned g_col1 = row_col(BK + lrow, tg, p.CG, g_ok1);
     const long long g_total = (long long)p.N * p.Dg * p.Hg * p.Wg;
 
     auto issue = [&](int ks, int stage) {
         const unsigned base = lds0 + stage * STAGE;
         const long long v0 = (long long)ks * BK;
-        {
-            const long long v = v0 + 4 * wv + lrow;
-            const unsigned off = (r_ok && v < p.V) ? (unsigned)v * (unsigned)(p.CRs * 2) + r_col : 0xffffffffu;
-            h3_dma16(rsR, base + (4 * wv) * 256, off, 0);
-        }
-        {
-            const long long g = v0 + delta + 4 * wv + lrow;
-            const unsigned off = (g_ok0 && g >= 0 && g < g_total) ? (unsigned)g * (unsigned)(p.CGs * 2) + g_col0 : 0xffffffffu;
-            h3_dma16(rsG, base + RSLAB + (4 * wv) * 256, off, 0);
+#pragma unroll
+        for (int k = 0; k < GPW; ++k) {
+            const int row0 = 4 * (wv + 8 * k);
+            {
+                const long long v = v0 + row0 + lrow;
+                const unsigned off = (r_ok && v < p.V) ? (unsigned)v * (unsigned)(p.CRs * 2) + r_col : 0xffffffffu;
+                h3_dma16(rsR, base + row0 * 256, off, 0);
+            }
+            {
+                const long long g = v0 + delta + row0 + lrow;
+                const unsigned off = (g_ok0 && g >= 0 && g < g_total) ? (unsigned)g * (unsigned)(p.CGs * 2) + g_col0 : 0xffffffffu;
+                h3_dma16(rsG, base + RSLAB + row0 * 256, off, 0);
+            }
         }
         if (wv == 0 && TG > 1) {
-            const long long g = v0 + delta + 32 + lrow;
+            const long long g = v0 + delta + BK + lrow;
             const unsigned off = (g_ok1 && g >= 0 && g < g_total) ? (unsigned)g * (unsigned)(p.CGs * 2) + g_col1 : 0xffffffffu;
-            h3_dma16(rsG, base + RSLAB + 32 * 256, off, 0);
+            h3_dma16(rsG, base + RSLAB + BK * 256, off, 0);
         }
     };
 
@@ -318,28 +383,76 @@ conv_wgrad_s1_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.0f;
 
-    static_assert(NS == 4, "the counted vmcnt immediates below assume 2 steps in flight");
+    // ---- main loop -----------------------------------------------------------------------------------------------------------
+    // A K-step = NSUB sub-steps of 16 voxels (2 + TG MFMA operand fragments, 2 TG MFMAs each).  The fragments of a sub-step are
+    // loaded during the previous one (two register sets), also across steps: the barrier that publishes step ks + 1 stands
+    // before the LAST sub-step of step ks, whose MFMAs run beside the loads of step ks + 1's first sub-step.  By then every
+    // wave has read all of stage(ks) into registers, so that stage is refilled with step ks + NS right behind the barrier:
+    // NS - 1 steps of flight time.  SIMD partners (waves w, w + 4) issue their pieces one sub-step apart (one's MFMAs cover
+    // the other's ~60-100 issue cycles per piece, conv3_halo_k32.hip).  Pieces per wave and step: 2 GPW (+ 1 for wave 0).
+    constexpr int NSUB = BK / 16;
+    constexpr int PPW = 2 * GPW;
+    bf16x8 af[2][2], bfr[2][TG];
+#define WG_LOAD(SET, SB, SUB)                                                                                  \
+    {                                                                                                          \
+        const unsigned so_ = (SB) + (SUB) * (16 * 256);                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                     \
+            const s16x4 a0_ = wg_tr_read(so_ + a_off[i_][0]);                                                  \
+            const s16x4 a1_ = wg_tr_read(so_ + a_off[i_][1]);                                                  \
+            af[SET][i_] = __builtin_shufflevector(a0_, a1_, 0, 1, 2, 3, 4, 5, 6, 7);                           \
+        }                                                                                                      \
+        _Pragma("unroll") for (int t_ = 0; t_ < TG; ++t_) {                                                    \
+            const s16x4 b0_ = wg_tr_read(so_ + b_off[t_][0]);                                                  \
+            const s16x4 b1_ = wg_tr_read(so_ + b_off[t_][1]);                                                  \
+            bfr[SET][t_] = __builtin_shufflevector(b0_, b1_, 0, 1, 2, 3, 4, 5, 6, 7);                          \
+        }                                                                                                      \
+    }
+#define WG_MFMA(SET, SUB)                                                                                      \
+    {                                                                                                          \
+        _Pragma("unroll") for (int t_ = 0; t_ < TG; ++t_) {                                                    \
+            bf16x8 b_ = bfr[SET][t_];                                                                          \
+            if (vmask[t_] != ~0ull) { /* wave-uniform */                                                       \
+                const unsigned byte_ = (unsigned)(vmask[t_] >> (16 * (SUB) + 8 * (lane >> 5))) & 0xffu;        \
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));                                    \
+                u32x4 m_;                                                                                      \
+                m_.x = wg_pair_mask(byte_);                                                                    \
+                m_.y = wg_pair_mask(byte_ >> 2);                                                               \
+                m_.z = wg_pair_mask(byte_ >> 4);                                                               \
+                m_.w = wg_pair_mask(byte_ >> 6);                                                               \
+                u32x4 bu_ = __builtin_bit_cast(u32x4, b_);                                                     \
+                bu_ &= m_;                                                                                     \
+                b_ = __builtin_bit_cast(bf16x8, bu_);                                                          \
+            }                                                                                                  \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                   \
+                acc[t_][i_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][i_], b_, acc[t_][i_], 0, 0, 0);  \
+        }                                                                                                      \
+    }
     if (k_begin < k_end) {
 #pragma unroll
-        for (int i = 0; i < NS - 1; ++i)
+        for (int i = 0; i < NS; ++i)
             if (k_begin + i < k_end) issue(k_begin + i, i);
+        // step k_begin has landed (NS - 1 later ones may be in flight)
+        {
+            const int later = min(k_end - k_begin, NS) - 1;          // wave-uniform
+            const bool extra = TG > 1 && wv == 0;
+            if (later >= 3) {
+                if (extra) wg_wait_vm<3 * (PPW + 1)>(); else wg_wait_vm<3 * PPW>();
+            } else if (later == 2) {
+                if (extra) wg_wait_vm<2 * (PPW + 1)>(); else wg_wait_vm<2 * PPW>();
+            } else if (later == 1) {
+                if (extra) wg_wait_vm<PPW + 1>(); else wg_wait_vm<PPW>();
+            } else {
+                wg_wait_vm<0>();
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        WG_LOAD(0, lds0, 0);
         int stage = 0;
         for (int ks = k_begin; ks < k_end; ++ks) {
-            // step ks must have landed; up to NS-2 later steps may stay in flight (2 DMAs per wave and step, 3 for wave 0)
-            if (ks + NS - 2 < k_end) {
-                if (TG > 1 && wv == 0)
-                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();   // data of step ks visible to all waves; everyone is done with step ks-1
-            if (ks + NS - 1 < k_end) issue(ks + NS - 1, stage == 0 ? NS - 1 : stage - 1);
-            // validity of (voxel, tap) pairs of this step: lane l decodes voxel 32*ks + (l & 31)
-            unsigned vmask[TG];
+            // validity of (voxel, tap) pairs of this step: lane l decodes voxel BK*ks + l
+            unsigned long long vmask[TG];
             {
-                const unsigned v = (unsigned)ks * BK + (lane & 31);
+                const unsigned v = (unsigned)ks * BK + (BK == 64 ? lane : (lane & 31));
                 const unsigned q1 = wg_div(v, p.mW, p.shW);
                 const int w = (int)(v - q1 * p.Wr);
                 const unsigned q2 = wg_div(q1, p.mH, p.shH);
@@ -349,45 +462,45 @@ conv_wgrad_s1_kernel(const WgradParams p) {
                 const bool dh = v < (unsigned)p.V && (unsigned)(d - p.pd + kd) < (unsigned)p.Dg &&
                                 (unsigned)(h - p.ph + kh) < (unsigned)p.Hg;
 #pragma unroll
-                for (int t = 0; t < TG; ++t)
-                    vmask[t] = (unsigned)__builtin_amdgcn_ballot_w64(dh && (unsigned)(w - p.pw + t) < (unsigned)p.Wg);
+                for (int t = 0; t < TG; ++t) {
+                    vmask[t] = __builtin_amdgcn_ballot_w64(dh && (unsigned)(w - p.pw + t) < (unsigned)p.Wg);
+                    if (BK == 32) vmask[t] |= 0xffffffff00000000ull;
+                }
             }
             const unsigned sb = lds0 + stage * STAGE;
+            const int nstage = stage + 1 == NS ? 0 : stage + 1;
+            const bool refill = ks + NS < k_end;                       // step ks + NS goes into this step's stage
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const unsigned so = sb + sub * (16 * 256);
-                bf16x8 af[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const s16x4 a0 = wg_tr_read(so + a_off[i][0]);
-                    const s16x4 a1 = wg_tr_read(so + a_off[i][1]);
-                    af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-#pragma unroll
-                for (int t = 0; t < TG; ++t) {
-                    const s16x4 b0 = wg_tr_read(so + b_off[t][0]);
-                    const s16x4 b1 = wg_tr_read(so + b_off[t][1]);
-                    bf16x8 bfr = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (vmask[t] != 0xffffffffu) {    // wave-uniform
-                        const unsigned byte = (vmask[t] >> (16 * sub + 8 * (lane >> 5))) & 0xffu;
-                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                        u32x4 m;
-                        m.x = wg_pair_mask(byte);
-                        m.y = wg_pair_mask(byte >> 2);
-                        m.z = wg_pair_mask(byte >> 4);
-                        m.w = wg_pair_mask(byte >> 6);
-                        u32x4 bu = __builtin_bit_cast(u32x4, bfr);
-                        bu &= m;
-                        bfr = __builtin_bit_cast(bf16x8, bu);
+            for (int sub = 0; sub < NSUB; ++sub) {
+                if (sub == NSUB - 1) {
+                    // step ks + 1 must have landed: the steps issued after it (ks + 2 .. ks + NS - 1) may stay in flight
+                    const int later = min(k_end - 1 - (ks + 1), NS - 2);   // wave-uniform, may be negative at the very end
+                    const bool extra = TG > 1 && wv == 0;
+                    if (NS == 4 && later >= 2) {
+                        if (extra) wg_wait_vm<2 * (PPW + 1)>(); else wg_wait_vm<2 * PPW>();
+                    } else if (later >= 1) {
+                        if (extra) wg_wait_vm<PPW + 1>(); else wg_wait_vm<PPW>();
+                    } else {
+                        wg_wait_vm<0>();
                     }
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[t][i], 0, 0, 0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks + 1 < k_end) WG_LOAD(0, lds0 + nstage * STAGE, 0);   // (NSUB is even: the last sub-step computes on set 1)
+                } else {
+                    if ((sub & 1) == 0) { WG_LOAD(1, sb, sub + 1); } else { WG_LOAD(0, sb, sub + 1); }
                 }
+                if ((sub & 1) == 0) { WG_MFMA(0, sub); } else { WG_MFMA(1, sub); }
+                __builtin_amdgcn_sched_barrier(0);
+                // refill of this step's stage (free since the barrier above): waves 0-3 behind the last sub-step, waves 4-7 behind
+                // the next step's first one
+                if (sub == NSUB - 1 && refill && wv < 4) issue(ks + NS, stage);
+                if (sub == 0 && wv >= 4 && ks > k_begin && ks - 1 + NS < k_end) issue(ks - 1 + NS, stage == 0 ? NS - 1 : stage - 1);
             }
-            stage = (stage + 1 == NS) ? 0 : stage + 1;
+            stage = nstage;
         }
     }
+#undef WG_LOAD
+#undef WG_MFMA
 
     const int CRp = p.tiles_r * BR, CGp = p.tiles_g * BG;
 #pragma unroll
@@ -439,6 +552,7 @@ static void wg_magic(unsigned d, unsigned* m, int* sh) {
 struct WgradGeom {
     int T, tiles_r, tiles_g, S, ksteps, kps;
     int tg;   // taps per block: KW for stride-1 'same' layers (conv_wgrad_s1_kernel), 0 = one tap per block (gather kernel)
+    int bk;   // voxels per K-step: 32 (gather kernel, conv_wgrad_s1_kernel<.., 32>) or 64
     long long V;
 };
 
@@ -457,16 +571,31 @@ static int wg_geometry(const ctsi_wgrad_desc* d, WgradGeom* g) {
     g->T = d->kd * d->kh * d->kw;
     g->tiles_r = (d->cr + wgk::BR - 1) / wgk::BR;
     g->tiles_g = (d->cg + wgk::BG - 1) / wgk::BG;
-    g->ksteps = (int)((g->V + wgk::BK - 1) / wgk::BK);
     g->tg = 0;
-    if (d->sh == 1 && d->sw == 1 && d->dr == d->dg && d->hr == d->hg && d->wr == d->wg && (d->kw == 3 || d->kw == 1) &&
-        getenv("CTSI_WGRAD_S1"))
-        g->tg = d->kw;   // opt-in: measured 10-20 % slower than the gather kernel on the config-3 shapes (1 block per CU)
+    g->bk = wgk::BK;
+    // Tap-sharing kernel (conv_wgrad_s1_kernel: one R slab + one halo'd G slab serve the 3 kw taps, 190 instead of 64 flop per
+    // byte of LDS fill, 8-wave blocks, one per CU).  Measured against the one-tap kernel (profiles/r02_notes.md): K-steps of
+    // 64 voxels + software-pipelined fragments + staggered DMA issue bring it from 10-20 % behind to par on the config-3
+    // shapes (653 / 715 / 606 / 767 vs 656 / 747 / 691 / 766 TFLOP/s) and ahead on long single-tile layers (128->128 @48x128^2:
+    // 830-867 vs 766-790): it is selected for those; CTSI_WGRAD_S1 = "0" | "32" | "64" overrides (off / K-step).
+    const char* s1 = getenv("CTSI_WGRAD_S1");
+    const bool s1_ok = d->sh == 1 && d->sw == 1 && d->dr == d->dg && d->hr == d->hg && d->wr == d->wg && (d->kw == 3 || d->kw == 1);
+    if (s1_ok && s1 && (atoi(s1) == 32 || atoi(s1) == 64 || atoi(s1) == 1)) {
+        g->tg = d->kw;
+        g->bk = atoi(s1) == 64 ? 64 : 32;
+    } else if (s1_ok && !s1 && d->kw == 3 && g->tiles_r * g->tiles_g == 1 && g->V >= 600000) {
+        g->tg = 3;
+        g->bk = 64;
+    }
+    g->ksteps = (int)((g->V + g->bk - 1) / g->bk);
     const int combos = (g->tg ? g->T / g->tg : g->T) * g->tiles_r * g->tiles_g;
-    const int target = g->tg ? 768 : 2048;         // blocks: 256 CUs x 3 (8-wave blocks) / x 8 (4-wave blocks).  Measured: 1024
+    const char* tgt = getenv("CTSI_WGRAD_TARGET");   // blocks to aim for (tuning aid)
+    const int target = tgt && atoi(tgt) > 0 ? atoi(tgt) : (g->tg ? 768 : 2048);         // blocks: 256 CUs x 3 (8-wave blocks) / x 8 (4-wave blocks).  Measured: 1024
                                                    // blocks (half the partial-sum traffic) is 10 % slower end to end (tail balance)
-    int S = (target + combos - 1) / combos;
-    const int smax = (g->ksteps + 15) / 16;        // at least 16 K-steps (512 voxels) per slice
+    // 8-wave blocks run one per CU: the grid must not spill a few blocks into another round (774 blocks = 4 rounds for the
+    // work of 3.02), so S rounds DOWN there; the 4-wave kernel (4-5 blocks per CU) keeps the round-1 rule
+    int S = g->tg ? target / combos : (target + combos - 1) / combos;
+    const int smax = (g->ksteps * (g->bk / 32) + 15) / 16;   // at least 512 voxels per slice
     if (S > smax) S = smax;
     if (S < 1) S = 1;
     g->kps = (g->ksteps + S - 1) / S;
@@ -508,15 +637,31 @@ extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* g
     wg_magic((unsigned)d->dr, &p.mD, &p.shD);
     const long long blocks = (long long)(g.tg ? g.T / g.tg : g.T) * g.tiles_r * g.tiles_g * g.S;
     CTSI_CHECK_ARG(blocks < (1ll << 31), "ctsi_wgrad: grid too large");
-    if (g.tg == 3)
-        hipLaunchKernelGGL(conv_wgrad_s1_kernel<3>, dim3((unsigned)blocks), dim3(wg3::NTH), wg3::LDS_BYTES,
-                           (hipStream_t)stream, p);
-    else if (g.tg == 1)
-        hipLaunchKernelGGL(conv_wgrad_s1_kernel<1>, dim3((unsigned)blocks), dim3(wg3::NTH), wg3::LDS_BYTES,
-                           (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(wgk::NTH), wgk::LDS_BYTES,
-                           (hipStream_t)stream, p);
+    if (g.tg) {
+        auto k = g.tg == 3 ? (g.bk == 64 ? conv_wgrad_s1_kernel<3, 64> : conv_wgrad_s1_kernel<3, 32>)
+                           : (g.bk == 64 ? conv_wgrad_s1_kernel<1, 64> : conv_wgrad_s1_kernel<1, 32>);
+        const int lds = g.bk == 64 ? wg3::Cfg<64>::LDS_BYTES : wg3::Cfg<32>::LDS_BYTES;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute((const void*)conv_wgrad_s1_kernel<3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)conv_wgrad_s1_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)conv_wgrad_s1_kernel<3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)conv_wgrad_s1_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(wg3::NTH), lds, (hipStream_t)stream, p);
+    } else
+    {
+        // 16x16x32 MFMAs by default: +1-3 % on every shape over the 32x32x16 form (interleaved runs, profiles/r02_notes.md):
+        // equal cycles, higher clock under load.  CTSI_WGRAD_SHAPE16=0 selects the 32x32x16 form (A/B timing)
+        const char* sh = getenv("CTSI_WGRAD_SHAPE16");
+        if (!(sh && atoi(sh) == 0))
+            hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3((unsigned)blocks), dim3(wgk::NTH), wgk::LDS_BYTES,
+                               (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3((unsigned)blocks), dim3(wgk::NTH), wgk::LDS_BYTES,
+                               (hipStream_t)stream, p);
+    }
     CTSI_LAUNCH_CHECK();
     const long long total = (long long)d->cr * d->cg * g.T;
     long long rb = (total + 255) / 256;

@@ -121,7 +121,7 @@ HALO3_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["16", "16h", "16h3", "16m", "32", "32m", "16k", "32k"])
+@pytest.mark.parametrize("tile", ["16", "16h", "16h3", "16m", "32", "32m", "16k", "32k", "32k3"])
 @pytest.mark.parametrize("name,c1,c2,cout,dims", HALO3_CASES, ids=[c[0] for c in HALO3_CASES])
 def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     """The LDS halo-tile 3x3x3 kernel (conv3_halo.hip) on aligned, ragged, multi-tile and two-source inputs;
@@ -140,9 +140,10 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     # "32k" / "16k": the same 512-voxel tiles on 16x16x32 MFMAs over tap pairs (conv3_halo_k32.hip)
     monkeypatch.setenv("CTSI_CONV_HALO_TILE", "32" if tile in ("16m", "16k") else tile[:2])   # ("16h3": the 192-voxel tile)
     monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile in ("16m", "16k") else "0")
-    monkeypatch.setenv("CTSI_CONV_K32", "1" if tile in ("32k", "16k") else "0")
+    monkeypatch.setenv("CTSI_CONV_K32", "1" if tile in ("32k", "16k", "32k3") else "0")
+    monkeypatch.setenv("CTSI_CONV_K32_384", "1" if tile == "32k3" else "0")                # its 3x4x32 = 384-voxel tile
     monkeypatch.setenv("CTSI_CONV_H32W16", {"16h": "1", "16h3": "2"}.get(tile, "0"))    # 4x4x16 / 3x4x16 tiles
-    monkeypatch.setenv("CTSI_CONV_M512", "1" if tile in ("32m", "16m", "32k", "16k") else "0")
+    monkeypatch.setenv("CTSI_CONV_M512", "1" if tile in ("32m", "16m", "32k", "16k", "32k3") else "0")
     y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=groups)
     assert rel_l2(y, ref) < CONV_TOL, name
     rg = ref.reshape(n, groups, -1).double()

@@ -43,7 +43,8 @@ struct HkCfg {
     static constexpr int STEP_TAPS = 2 * UPS;
     static constexpr int WSLOT_BYTES = STEP_TAPS * TAP_BYTES;   // 16384
     static constexpr int NWS = 4;                           // three steps in flight + the one being read
-    static constexpr int NWAVE = BM / 64;
+    static constexpr int NWAVE = 8;
+    static constexpr int MA = BM / 128;                     // 16-voxel A tiles per wave: 4 (512-voxel tile) or 3 (384)
     static constexpr int NTH = 64 * NWAVE;
     static constexpr int NPIECE = (HALO_INSTR + NWAVE - 1) / NWAVE;   // halo DMAs per wave and chunk
     static constexpr int OFF_W = 2 * HALO_BYTES;
@@ -52,8 +53,8 @@ struct HkCfg {
     static constexpr int OFF_CS = OFF_ROW + BM * 8;
     static constexpr int LDS_BYTES = OFF_CS + NWAVE * BN * 8;
     static constexpr int LPW = 64 / TW;                     // W-lines per wave
-    static_assert(NWAVE == 8 && NPIECE <= 5 && TH % LPW == 0 && LDS_BYTES <= 160 * 1024 && WSLOT_BYTES == 16384 &&
-                      (UPS == 2 || UPS == 4), "unsupported tile");
+    static_assert(BM % 128 == 0 && (MA == 3 || (MA == 4 && TH % LPW == 0)) && NPIECE <= 5 && LDS_BYTES <= 160 * 1024 &&
+                      WSLOT_BYTES == 16384 && (UPS == 2 || UPS == 4), "unsupported tile");
     // A tile i (rows [16 i, 16 i + 16) of the wave's 64): halo-voxel offset from the wave's first voxel
     static constexpr int a_imm(int i) { return (((16 * i) / TW) * HW + (16 * i) % TW) * 32; }
 };
@@ -81,6 +82,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     using Cfg = HkCfg<TD_, TH_, TW_, BN_, UPS_>;
     constexpr int UPS = Cfg::UPS, NJ = Cfg::NJ, NJH = Cfg::NJ / 2, STEP_TAPS = Cfg::STEP_TAPS;
     constexpr int TAPS = TR ? 12 : 27;                       // entries per 16-channel chunk
+    constexpr int MA = Cfg::MA;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, HH = Cfg::HH, HW = Cfg::HW, HV = Cfg::HV;
     constexpr int HALO_INSTR = Cfg::HALO_INSTR, HALO_BYTES = Cfg::HALO_BYTES, BM = Cfg::BM, BN = Cfg::BN;
     constexpr int TAP_BYTES = Cfg::TAP_BYTES, WSLOT_BYTES = Cfg::WSLOT_BYTES, NWS = Cfg::NWS, NWAVE = Cfg::NWAVE;
@@ -121,7 +123,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const int tW = r0 - tH * p.tilesW;
     const int d0 = tD * Cfg::TD, h0 = tH * TH, w0 = tW * TW;
 
-    {   // row = line * TW + m, line = ld * TH + lh
+    if (tid < BM) {   // row = line * TW + m, line = ld * TH + lh
         const int mm = tid % TW, line = tid / TW;
         const int d = d0 + line / TH, h = h0 + line % TH, w = w0 + mm;
         long long off = -1;
@@ -203,9 +205,21 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const int r16 = lane & 15, kg = lane >> 4;
     const bool tap1 = kg >= 2;
     int a_lane, b_lane;
-    {
-        const int line0 = wave * Cfg::LPW;
-        const int vbase = ((line0 / TH) * HH + (line0 % TH)) * HW;
+    int aoff[MA];                                            // byte offset of A tile i from the wave's first voxel: immediates for
+    {                                                        // the 512-voxel tiles, wave-uniform registers for 384 (48 rows per
+        auto hv = [&](int row) {                             // wave = 1.5 W-lines of 32: the split depends on the wave's parity)
+            const int line = row / TW, wofs = row % TW;
+            return ((line / TH) * HH + (line % TH)) * HW + wofs;
+        };
+        const int row0 = wave * 16 * MA;
+        const int vbase = hv(row0);
+#pragma unroll
+        for (int i = 0; i < MA; ++i) {
+            if constexpr (MA == 4)
+                aoff[i] = Cfg::a_imm(i);
+            else
+                aoff[i] = (hv(row0 + 16 * i) - vbase) * 32;
+        }
         a_lane = (vbase + r16) * 32 + (kg & 1) * 16;
         b_lane = OFF_W + (kg >> 1) * TAP_BYTES + r16 * 32 + (kg & 1) * 16;
     }
@@ -228,21 +242,21 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         return (cc & 1) * HALO_BYTES + ((kd * HH + kh) * HW + kw) * 32;
     };
 
-    f32x4 acc[4][NJ];
+    f32x4 acc[MA][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MA; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.0f;
 
-    bf16x8 fa0[4], fa1[4], fbl[NJH], fbh[NJH];
+    bf16x8 fa0[MA], fa1[MA], fbl[NJH], fbh[NJH];
 
     // A fragments i0, i0 + 1 of a unit into FA; B fragments j0 .. j0 + NJH - 1 of unit `uu` of the step at BADDR into FB
 #define HK_LOAD_A(FA, I0, AADDR)                                                                               \
     {                                                                                                          \
-        FA[I0] = *reinterpret_cast<const bf16x8*>(smem + (AADDR) + Cfg::a_imm(I0));                            \
-        FA[I0 + 1] = *reinterpret_cast<const bf16x8*>(smem + (AADDR) + Cfg::a_imm(I0 + 1));                    \
+        _Pragma("unroll") for (int i_ = (I0); i_ < ((I0) == 0 ? 2 : MA); ++i_)                                 \
+            FA[i_] = *reinterpret_cast<const bf16x8*>(smem + (AADDR) + aoff[i_]);                              \
     }
 #define HK_LOAD_B(FB, J0, BADDR, UU)                                                                           \
     {                                                                                                          \
@@ -251,7 +265,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     }
 #define HK_MFMA(FA, FB, J0)                                                                                    \
     {                                                                                                          \
-        _Pragma("unroll") for (int j_ = 0; j_ < NJH; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)     \
+        _Pragma("unroll") for (int j_ = 0; j_ < NJH; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < MA; ++i_)    \
             acc[i_][(J0) + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[i_], FB[j_], acc[i_][(J0) + j_], 0, 0, 0); \
     }
     // a phase: 4 NJH MFMAs with its NJH + 2 ds_read_b128 in the first gaps (they feed the NEXT phase)
@@ -262,7 +276,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
         }                                                                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJH - (NJH + 2), 0);                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, MA * NJH - (NJH + 2), 0);                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
 
@@ -374,9 +388,9 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const bool want_sums = p.colsum != nullptr;
     unsigned vbits = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MA; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) vbits |= (unsigned)(s_rowoff[wave * 64 + 16 * i + 4 * kg + q] >= 0) << (4 * i + q);
+        for (int q = 0; q < 4; ++q) vbits |= (unsigned)(s_rowoff[wave * 16 * MA + 16 * i + 4 * kg + q] >= 0) << (4 * i + q);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int col = j * 16 + r16;
@@ -384,8 +398,8 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16_t* trow = s_tile + (wave * 64 + 16 * i + 4 * kg) * BN + col;
+        for (int i = 0; i < MA; ++i) {
+            bf16_t* trow = s_tile + (wave * 16 * MA + 16 * i + 4 * kg) * BN + col;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float v = acc[i][j][q] + bv;
@@ -503,9 +517,12 @@ static void hk_launch(const Conv3HaloParams* hp, hipStream_t stream) {
     hipLaunchKernelGGL(k, dim3((TR ? 4 : 1) * hp->mtiles * hp->ntiles_n), dim3(Cfg::NTH), Cfg::LDS_BYTES, stream, *hp);
 }
 
-extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16 */, int bn, void* stream) {
-    CTSI_CHECK_ARG(bn == 128, "ctsi_conv3_halo_k32_launch: bad BN %d", bn);
-    if (hp->tr) {
+extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16, 3: 3x4x32 */, int bn,
+                                          void* stream) {
+    CTSI_CHECK_ARG(bn == 128 && (tile != 3 || !hp->tr), "ctsi_conv3_halo_k32_launch: bad BN %d / tile %d", bn, tile);
+    if (tile == 3) {
+        hk_launch<3, 4, 32, 128, 2, false>(hp, (hipStream_t)stream);
+    } else if (hp->tr) {
         if (tile == 2)
             hk_launch<4, 8, 16, 128, 2, true>(hp, (hipStream_t)stream);
         else

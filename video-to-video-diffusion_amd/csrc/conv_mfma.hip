@@ -897,6 +897,27 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 const char* nin = getenv("CTSI_CONV_NORM_IN");
                 if (!(k32 && !strcmp(k32, "0")) && !(nin && atoi(nin) == 1)) p->halo3 = 7;
             }
+            {   // 384-voxel tile (3x4x32, 48 voxels per wave) of the k32 kernel where 512-voxel tiles fill the CUs badly: the
+                // 48x32x32 x 512-cout layers are 384 blocks of 512 x 128 (1.5 rounds of the 256 CUs) or 512 blocks of 384 x 128
+                // (2 rounds).  Relative efficiencies on full grids: 4x2x32 / 32x32x16 MFMAs 1.0, k32 512-voxel 1.15, k32 384-voxel 1.1
+                const char* k32 = getenv("CTSI_CONV_K32");
+                const char* nin = getenv("CTSI_CONV_NORM_IN");
+                const char* t384 = getenv("CTSI_CONV_K32_384");   // "0" | "1" (tuning / test aid)
+                const double cur = p->halo3 == 7 ? (p->m512_w16 == 2 ? score(4, 8, 16, 1.15) : score(4, 4, 32, 1.15))
+                                   : p->halo3 == 5 ? 1.0e9
+                                   : p->halo3 == 2 ? (p->h32_w16 == 2 ? score(3, 4, 16, 0.95) : p->h32_w16 == 1 ? score(4, 4, 16, 1.0) : s32)
+                                                   : s16;
+                bool use384 = score(3, 4, 32, 1.1) > cur;
+                if (t384 && !strcmp(t384, "0")) use384 = false;
+                if (t384 && !strcmp(t384, "1")) use384 = true;
+                if ((k32 && !strcmp(k32, "0")) || (nin && atoi(nin) == 1)) use384 = false;
+                if (use384) {
+                    p->halo3 = 7;
+                    p->BM = 384;
+                    p->h32_w16 = 0;
+                    p->m512_w16 = 3;
+                }
+            }
         }
         // ConvTranspose3d (3,4,4) / (1,2,2) on the k32 kernel: each parity class is a 12-tap convolution on the input grid with
         // the 3x3x3 conv's halo tile (conv3_halo_k32.hip, TR = true); CTSI_CONV_K32T=0 keeps the gather kernel (A/B timing)
@@ -930,7 +951,9 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
-    if ((p->halo3 == 5 || p->halo3 == 7) && p->m512_w16 == 2) {
+    if (p->halo3 == 7 && p->m512_w16 == 3) {
+        p->TD = 3; p->TH = 4; p->TW = 32;
+    } else if ((p->halo3 == 5 || p->halo3 == 7) && p->m512_w16 == 2) {
         p->TD = 4; p->TH = 8; p->TW = 16;
     } else if (p->halo3 == 5 || p->halo3 == 7) {
         p->TD = 4; p->TH = 4; p->TW = 32;

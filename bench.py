@@ -345,7 +345,6 @@ def main():
             dom_key, dom = max(variants.items(), key=lambda kv: kv[1][2])   # dominant kernel = most time per step
             kernel_names = {"m9t": "conv3_halo_k32_kernel<TR> (ConvTranspose3d (3,4,4)/(1,2,2), 12 entries per chunk, four parity classes)",
                             "m9": "conv3_halo_k32_kernel (3x3x3 LDS halo tile 4x4x32 x 128 couts, 16-ch chunks, tap pairs on mfma_16x16x32_bf16)",
-                            "m7": "conv3_halo32m_kernel (3x3x3 LDS halo tile 4x4x32 x 128 couts, 16-ch chunks, mfma_32x32x16_bf16)",
                             "m4": "conv3_halo32_kernel (3x3x3 LDS halo tile 4x2x32, mfma_32x32x16_bf16)",
                             "m3": "conv3_halo_kernel (3x3x3 LDS halo tile 4x4x16, mfma_16x16x32_bf16)"}
             dom_name = kernel_names.get(dom_key.rsplit("_", 1)[-1], "conv_gather_mfma_kernel " + dom_key)

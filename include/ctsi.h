@@ -103,23 +103,6 @@ typedef struct ctsi_conv_out {
     float gn_eps;
     long long gn_count;      /* elements per (sample, group) the statistics were taken over                       */
     int gn_silu;             /* 1: SiLU after the add                                                             */
-    /* optional normalise-on-load of the INPUT (plans for which ctsi_conv_plan_supports_norm_in() is 1: the 512-voxel
-     * halo-tile kernel, single source): x1 is the RAW output of the previous conv and the kernel applies
-     *     x = silu?( gn(x1) * gamma + beta ) + tbias[row][c]
-     * to every element of the staged input tile in LDS, so `Conv3DBlock`'s GroupNorm + SiLU and the ResBlock's time-bias
-     * add (models/unet3d.py:70-74, 123-125; models/vae.py:31-35, 50-56) between two convs never touch HBM.  Same
-     * arithmetic, same bf16 rounding as ctsi_gn_apply followed by the conv: bit-identical results.                    */
-    const double* nin_sums;  /* [n][groups][2] fp64 (sum, sumsq) of x1; NULL = plain input                              */
-    const float* nin_gamma;
-    const float* nin_beta;
-    const float* nin_tbias;  /* or NULL; row used for sample i: (nin_step_ptr ? *nin_step_ptr : 0) * n + i              */
-    const int* nin_step_ptr;
-    int nin_tb_stride;
-    int nin_groups;
-    int nin_silu;
-    float nin_eps;
-    long long nin_count;     /* elements per (sample, group) the statistics were taken over                            */
-    int nin_pad_lo, nin_pad_hi; /* halo_d inputs: the first / last depth slice is a volume end (stays zero padding)    */
 } ctsi_conv_out;
 
 int ctsi_conv_plan_create(ctsi_conv_plan** plan, const ctsi_conv_desc* desc);
@@ -137,8 +120,6 @@ int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* plan);
 int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* plan);
 /* algorithmic FLOPs (2*MAC, dense direct convolution) of one forward of this layer */
 double ctsi_conv_plan_flops(const ctsi_conv_plan* plan);
-/* 1 when ctsi_conv_fwd accepts ctsi_conv_out.nin_* for this plan (normalise-on-load of the input) */
-int ctsi_conv_plan_supports_norm_in(const ctsi_conv_plan* plan);
 /* which kernel variant the plan launches: MFMA tile (bm x bn) and staging mode
  * (0: general gather, 1: small-cin tap-packed K, 2: buffer-addressed whole-chunk gather)      */
 int ctsi_conv_plan_config(const ctsi_conv_plan* plan, int* bm, int* bn, int* mode);

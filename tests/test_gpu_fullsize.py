@@ -56,10 +56,10 @@ def G():
 #     remap), including the GroupNorm column sums its epilogue emits
 # --------------------------------------------------------------------------------------------------------------------
 REAL_SHAPES = [
-    ("L0_128_128_48x128x128", 128, 0, 128, (1, 48, 128, 128)),      # conv3_halo32m<4,4,32>: 20 launches per step
+    ("L0_128_128_48x128x128", 128, 0, 128, (1, 48, 128, 128)),      # conv3_halo_k32<4,4,32>: 21 launches per step
     ("L0_concat_256+128_to_128", 256, 128, 128, (1, 48, 128, 128)),  # decoder level 3, first block (two sources)
     ("L1_256_256_48x64x64", 256, 0, 256, (1, 48, 64, 64)),
-    ("L2_512_512_48x32x32", 512, 0, 512, (1, 48, 32, 32)),           # conv3_halo32 (4x2x32 tile)
+    ("L2_512_512_48x32x32", 512, 0, 512, (1, 48, 32, 32)),           # conv3_halo_k32<3,4,32>: the 384-voxel tile
     ("L3_512_512_48x16x16", 512, 0, 512, (1, 48, 16, 16)),           # 16-wide level
 ]
 

@@ -121,7 +121,7 @@ HALO3_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["16", "16h", "16h3", "16m", "32", "32m", "16k", "32k", "32k3"])
+@pytest.mark.parametrize("tile", ["16", "16h", "16h3", "32", "16k", "32k", "32k3"])
 @pytest.mark.parametrize("name,c1,c2,cout,dims", HALO3_CASES, ids=[c[0] for c in HALO3_CASES])
 def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     """The LDS halo-tile 3x3x3 kernel (conv3_halo.hip) on aligned, ragged, multi-tile and two-source inputs;
@@ -136,14 +136,14 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     groups = 8
     monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
     # "16": 4x4x16 tile (16x16x32 MFMA); "16h": 4x4x16 tile on the 32x32x16-MFMA kernel (two W-lines per A tile); "32":
-    # 4x2x32 tile (32x32x16 MFMA); "32m" / "16m": the 512-voxel kernel in its 4x4x32 / 4x8x16 form.  (The measured-slower round-1 variants live under csrc/experiments/ and are not built in.)
-    # "32k" / "16k": the same 512-voxel tiles on 16x16x32 MFMAs over tap pairs (conv3_halo_k32.hip)
-    monkeypatch.setenv("CTSI_CONV_HALO_TILE", "32" if tile in ("16m", "16k") else tile[:2])   # ("16h3": the 192-voxel tile)
-    monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile in ("16m", "16k") else "0")
-    monkeypatch.setenv("CTSI_CONV_K32", "1" if tile in ("32k", "16k", "32k3") else "0")
-    monkeypatch.setenv("CTSI_CONV_K32_384", "1" if tile == "32k3" else "0")                # its 3x4x32 = 384-voxel tile
+    # 4x2x32 tile (32x32x16 MFMA); "32k" / "16k": the 512-voxel tile (4x4x32 / 4x8x16) on 16x16x32 MFMAs over tap pairs
+    # (conv3_halo_k32.hip); "32k3": its 3x4x32 = 384-voxel tile.  (Measured-slower variants -- round 1's persistent / half-size
+    # blocks, the 32x32x16 form of the 512-voxel tile -- live under csrc/experiments/ and are not built in.)
+    monkeypatch.setenv("CTSI_CONV_HALO_TILE", "32" if tile == "16k" else tile[:2])   # ("16h3": the 192-voxel tile)
+    monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile == "16k" else "0")
+    monkeypatch.setenv("CTSI_CONV_K32_384", "1" if tile == "32k3" else "0")
     monkeypatch.setenv("CTSI_CONV_H32W16", {"16h": "1", "16h3": "2"}.get(tile, "0"))    # 4x4x16 / 3x4x16 tiles
-    monkeypatch.setenv("CTSI_CONV_M512", "1" if tile in ("32m", "16m", "32k", "16k", "32k3") else "0")
+    monkeypatch.setenv("CTSI_CONV_M512", "1" if tile in ("32k", "16k", "32k3") else "0")
     y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=groups)
     assert rel_l2(y, ref) < CONV_TOL, name
     rg = ref.reshape(n, groups, -1).double()
@@ -266,59 +266,6 @@ def test_conv_linearity_and_zero_padding_property(G):
     y, _ = G.run_conv(ones, None, wsum, None)
     ref = F.conv3d(ones, wsum, None, padding=1)   # 27 inside, 18/12/8 on faces/edges/corners
     assert torch.equal(y, bf16_round(ref))
-
-
-@pytest.mark.parametrize("dims,cin,cmid,cout,tb", [((1, 5, 9, 40), 64, 128, 128, True), ((2, 4, 8, 32), 32, 64, 256, False),
-                                                   ((1, 6, 8, 48), 128, 128, 64, True)])
-def test_normalise_on_load_is_bit_identical(G, monkeypatch, dims, cin, cmid, cout, tb):
-    """conv -> GroupNorm + SiLU (+ time bias) -> conv with the normalisation applied to the staged halo tile inside the second
-    conv (ctsi_conv_out.nin_*, the 512-voxel kernel) == the same chain with ctsi_gn_apply as its own pass: same arithmetic, same
-    bf16 rounding, bit for bit; ragged edges, batch 2, 16- and 32-wide tiles."""
-    import importlib
-    E = importlib.import_module("video-to-video-diffusion_amd.engine")
-    n, d, h, w = dims
-    x = bf16_round(formula_input((n, cin, d, h, w), 51))
-    w1 = bf16_round(_w((cmid, cin, 3, 3, 3), 52))
-    w2 = bf16_round(_w((cout, cmid, 3, 3, 3), 53))
-    b1, b2 = formula_input((cmid,), 54) * 0.1, formula_input((cout,), 55) * 0.1
-    gn = torch.nn.GroupNorm(8, cmid)
-    with torch.no_grad():
-        gn.weight.copy_(1.0 + 0.2 * formula_input((cmid,), 56))
-        gn.bias.copy_(0.1 * formula_input((cmid,), 57))
-    tbias = (formula_input((3 * n, cmid + 8), 58) * 0.3).to("cuda:0")     # rows x (offset 8 + cmid) : exercises off / stride
-    step = torch.tensor([1], dtype=torch.int32, device="cuda:0")
-    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
-    monkeypatch.setenv("CTSI_CONV_M512", "1")
-    monkeypatch.setenv("CTSI_CONV_K32", "0")        # both chains on conv3_halo32m_kernel, the one that implements the rewrite
-    outs, kinds = [], []
-    for fused in (True, False):
-        monkeypatch.setenv("CTSI_CONV_NORM_IN", "1" if fused else "0")     # (opt-in: measured slower end to end)
-        c = G.ctx()
-        with c.scope():
-            prog = E.Program(c)
-            a = G.to_act(prog, x)
-            c1, st = prog.conv("c1", lambda: w1, lambda: b1, a, None, cout=cmid, want_stats=True)
-            slot = prog.gn_finalize(c1, 8, st)
-            tbarg = (tbias, 8, cmid + 8, step) if tb else None
-            c2, st2 = prog.conv("c2", lambda: w2, lambda: b2, c1, None, cout=cout, want_stats=True,
-                                norm_in=(slot, gn.to("cuda:0"), True, tbarg))
-            slot2 = prog.gn_finalize(c2, 8, st2)
-            prog.finalize_layout()
-            prog.run()
-            outs.append((G.from_act(prog, c2).cpu(), prog._gn_sums[slot2:slot2 + n * 16].clone().cpu()))
-            kinds.append([m[0] for m in prog.op_meta])
-        torch.cuda.synchronize()
-    assert any(k.endswith("+gn_in") for k in kinds[0]) and "gn.apply" not in kinds[0]
-    assert "gn.apply" in kinds[1]
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    # and against torch on the same bf16-rounded operands
-    h1 = F.conv3d(x, w1, b1, padding=1)
-    h1 = bf16_round(h1)
-    hn = F.silu(F.group_norm(h1, 8, gn.weight.cpu(), gn.bias.cpu(), eps=gn.eps))
-    if tb:
-        hn = hn + tbias.cpu()[n:2 * n, 8:].reshape(n, cmid, 1, 1, 1)
-    ref = F.conv3d(bf16_round(hn), w2, b2, padding=1)
-    assert rel_l2(outs[0][0], ref) < 6e-3
 
 
 def test_groupnorm_statistics_are_bit_stable(G):

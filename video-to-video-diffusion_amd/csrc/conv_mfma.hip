@@ -647,7 +647,7 @@ struct ctsi_conv_plan {
     int tap_margin[4], ad_min[4];
     int fast, dshift;
     int h32_w16;    // halo3 == 2 only: 1 = 4x4x16 tile (two W-lines of 16 per A tile), 2 = 3x4x16 tile, instead of 4x2x32
-    int m512_w16;   // halo3 == 5 only: 2 = 4x8x16 tile instead of 4x4x32
+    int m512_w16;   // halo3 == 7 only: tile of the k32 kernel: 0 = 4x4x32, 2 = 4x8x16, 3 = 3x4x32 (384 voxels)
     int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip); 5: 512-voxel tile
                 // (conv3_halo_m512.hip).  3 / 4 were the persistent-block and half-size-block experiments, now under
                 // csrc/experiments/ (measured slower, profiles/r01_notes.md) and no longer built into libctsi.so.
@@ -890,27 +890,21 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             p->halo3 = pick;
             if (pick == 5) {
                 p->BM = 512;
-                // the 512-voxel tile runs on v_mfma_f32_16x16x32_bf16 over tap pairs (conv3_halo_k32.hip: +10-12 % over the
-                // 32x32x16 form on real data, profiles/r02_notes.md); CTSI_CONV_K32=0 selects conv3_halo32m_kernel (A/B timing,
-                // and the opt-in normalise-on-load experiment, which only that kernel implements)
-                const char* k32 = getenv("CTSI_CONV_K32");
-                const char* nin = getenv("CTSI_CONV_NORM_IN");
-                if (!(k32 && !strcmp(k32, "0")) && !(nin && atoi(nin) == 1)) p->halo3 = 7;
+                // the 512-voxel tile runs on v_mfma_f32_16x16x32_bf16 over tap pairs (conv3_halo_k32.hip: +10-12 % on real data
+                // over the 32x32x16 form conv3_halo32m_kernel, which -- with its normalise-on-load experiment -- now lives
+                // under csrc/experiments/, outside libctsi.so; profiles/r02_notes.md)
+                p->halo3 = 7;
             }
             {   // 384-voxel tile (3x4x32, 48 voxels per wave) of the k32 kernel where 512-voxel tiles fill the CUs badly: the
                 // 48x32x32 x 512-cout layers are 384 blocks of 512 x 128 (1.5 rounds of the 256 CUs) or 512 blocks of 384 x 128
                 // (2 rounds).  Relative efficiencies on full grids: 4x2x32 / 32x32x16 MFMAs 1.0, k32 512-voxel 1.15, k32 384-voxel 1.1
-                const char* k32 = getenv("CTSI_CONV_K32");
-                const char* nin = getenv("CTSI_CONV_NORM_IN");
                 const char* t384 = getenv("CTSI_CONV_K32_384");   // "0" | "1" (tuning / test aid)
                 const double cur = p->halo3 == 7 ? (p->m512_w16 == 2 ? score(4, 8, 16, 1.15) : score(4, 4, 32, 1.15))
-                                   : p->halo3 == 5 ? 1.0e9
                                    : p->halo3 == 2 ? (p->h32_w16 == 2 ? score(3, 4, 16, 0.95) : p->h32_w16 == 1 ? score(4, 4, 16, 1.0) : s32)
                                                    : s16;
                 bool use384 = score(3, 4, 32, 1.1) > cur;
                 if (t384 && !strcmp(t384, "0")) use384 = false;
                 if (t384 && !strcmp(t384, "1")) use384 = true;
-                if ((k32 && !strcmp(k32, "0")) || (nin && atoi(nin) == 1)) use384 = false;
                 if (use384) {
                     p->halo3 = 7;
                     p->BM = 384;
@@ -953,9 +947,9 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     p->ntiles_n = p->CoutPad / p->BN;
     if (p->halo3 == 7 && p->m512_w16 == 3) {
         p->TD = 3; p->TH = 4; p->TW = 32;
-    } else if ((p->halo3 == 5 || p->halo3 == 7) && p->m512_w16 == 2) {
+    } else if (p->halo3 == 7 && p->m512_w16 == 2) {
         p->TD = 4; p->TH = 8; p->TW = 16;
-    } else if (p->halo3 == 5 || p->halo3 == 7) {
+    } else if (p->halo3 == 7) {
         p->TD = 4; p->TH = 4; p->TW = 32;
     } else if (p->halo3 == 2) {
         p->TD = p->h32_w16 == 2 ? 3 : 4; p->TH = p->h32_w16 ? 4 : 2; p->TW = p->h32_w16 ? 16 : 32;
@@ -1019,16 +1013,6 @@ extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) { return p ? p->ncl
 extern "C" int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* p) { return p ? p->tps : 0; }
 extern "C" int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* p) { return p ? p->CoutPad : 0; }
 extern "C" double ctsi_conv_plan_flops(const ctsi_conv_plan* p) { return p ? p->flops : 0.0; }
-extern "C" int ctsi_conv_plan_supports_norm_in(const ctsi_conv_plan* p) {
-    // the 512-voxel halo-tile kernel, one source, coefficient tables (3 floats per channel) within the LDS left over.
-    // OPT-IN (CTSI_CONV_NORM_IN=1): bit-identical to the separate GroupNorm pass, but measured SLOWER end to end -- the in-LDS
-    // rewrite costs ~158 us per 0.6 ms launch (its ~670-cycle read / VALU / write chain per piece sits on every wave's
-    // critical path; placing it on one SIMD partner at a time hides none of it) against 69 us saved per skipped gn_apply:
-    // +0.9 ms per step.  Kept for a future version that interleaves the rewrite with the MFMA phases instruction by
-    // instruction (profiles/r02_notes.md).
-    const char* on = getenv("CTSI_CONV_NORM_IN");
-    return p && p->halo3 == 5 && p->d.c2 == 0 && p->d.c1 <= 1024 && on && atoi(on) == 1 ? 1 : 0;
-}
 extern "C" int ctsi_conv_plan_config(const ctsi_conv_plan* p, int* bm, int* bn, int* mode) {
     CTSI_CHECK_ARG(p, "ctsi_conv_plan_config: null plan");
     if (bm) *bm = p->BM;
@@ -1048,7 +1032,6 @@ extern "C" int ctsi_conv_plan_set_weight_cin(ctsi_conv_plan* p, int cin_w) {
 extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float* w, void* packed,
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
-    if (p->halo3 == 5) return ctsi_conv3_halo_c16_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
     if (p->halo3 == 7)
         return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, p->BN, p->d.transposed, stream);
     if (p->halo3 == 6) {
@@ -1129,12 +1112,6 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
                        "ctsi_conv_fwd: bf16 output needs cout, cout_stride, c_off multiples of 8 "
                        "(cout=%d stride=%d off=%d)", p->d.cout, o->cout_stride, o->c_off);
     }
-    if (o->nin_sums != nullptr) {
-        CTSI_CHECK_ARG(ctsi_conv_plan_supports_norm_in(p) && o->mode == 0 && o->act == 0,
-                       "ctsi_conv_fwd: this plan does not support normalise-on-load (see ctsi_conv_plan_supports_norm_in)");
-        CTSI_CHECK_ARG(o->nin_gamma && o->nin_beta && o->nin_groups > 0 && p->d.c1 % o->nin_groups == 0 && o->nin_count > 0,
-                       "ctsi_conv_fwd: bad normalise-on-load arguments (groups=%d, c1=%d)", o->nin_groups, p->d.c1);
-    }
     if (o->gn_x != nullptr) {
         CTSI_CHECK_ARG(!p->halo3 && o->mode == 0 && o->act == 0 && o->colsum == nullptr && p->nclass == 1,
                        "ctsi_conv_fwd: the fused GroupNorm tail needs a gather-kernel plan, bf16 output, no act / colsum");
@@ -1157,7 +1134,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         h.dshift = p->dshift;
         h.tilesD = p->tilesD; h.tilesH = p->tilesH; h.tilesW = p->tilesW; h.tps = p->tps; h.mtiles = p->mtiles;
         h.ntiles_n = p->ntiles_n;
-        h.nchunks = p->Cin / (p->halo3 == 5 || p->halo3 == 7 ? 16 : 32);
+        h.nchunks = p->Cin / (p->halo3 == 7 ? 16 : 32);
         h.Cout = p->d.cout; h.CoutPad = p->CoutPad;
         h.cout_stride = o->cout_stride; h.c_off = o->c_off;
         {   // n-major block order (one n-tile's 3.5 MB weight slab at a time per XCD instead of all of them: the 48x32x32 /
@@ -1175,22 +1152,8 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
         }
-        h.nin_sums = o->nin_sums;
-        h.nin_gamma = o->nin_gamma;
-        h.nin_beta = o->nin_beta;
-        h.nin_tbias = o->nin_tbias;
-        h.nin_step_ptr = o->nin_step_ptr;
-        h.nin_tb_stride = o->nin_tb_stride;
-        h.nin_groups = o->nin_groups;
-        h.nin_silu = o->nin_silu;
-        h.nin_n_total = p->d.n;
-        h.nin_pad_lo = o->nin_pad_lo;
-        h.nin_pad_hi = o->nin_pad_hi;
-        h.nin_eps = o->nin_eps;
-        h.nin_count = (double)o->nin_count;
         if (p->halo3 == 6)
             return ctsi_conv3_head_launch(&h, p->d.cout <= 8 ? 8 : 16, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
-        if (p->halo3 == 5) return ctsi_conv3_halo_m512_launch(&h, p->m512_w16, stream);
         h.tr = p->d.transposed;
         if (p->halo3 == 7) return ctsi_conv3_halo_k32_launch(&h, p->m512_w16, p->BN, stream);
         return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? (p->h32_w16 == 2 ? 4 : (p->h32_w16 ? 3 : 1)) : 0, stream);

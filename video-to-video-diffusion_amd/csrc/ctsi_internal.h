@@ -90,7 +90,7 @@ struct Conv3HaloParams {
     int dbg;              // ablation bits (0 in production): 1 no halo DMA after chunk 0, 2 no weight DMA after step 1, 4 no
                           // global stores, 8 no epilogue (1-8: wrong results, timing only); 16 / 32: DMA pieces issued right behind
                           // the step's barrier / at the end of the step instead of behind the first MFMA phase (correct results)
-    // normalise-on-load (conv3_halo32m_kernel, single source): the input is the RAW output of the previous conv; the kernel
+    // normalise-on-load (experiments/conv3_halo_m512.hip only; no kernel of libctsi.so reads these): the input is the RAW output of the previous conv; the kernel
     // applies y = silu?(x * gamma * rstd + (beta - mean * gamma * rstd)) + tbias to every halo-tile element in LDS right after
     // its DMA has landed, i.e. the GroupNorm + SiLU + time-bias pass between two convs never touches HBM.
     const double* nin_sums;   // [n][groups][2] fp64 (sum, sumsq) of the input; NULL = plain input
@@ -108,11 +108,8 @@ struct Conv3HaloParams {
 extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
                                     void* stream);
 extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void* stream);
-extern "C" int ctsi_conv3_halo_c16_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,
-                                        void* stream);
 extern "C" int ctsi_conv3_head_launch(const Conv3HaloParams* hp, int rows, int out_mode, int act, long long sn, long long sc,
                                       long long sd, long long sh, long long sw, void* stream);
-extern "C" int ctsi_conv3_halo_m512_launch(const Conv3HaloParams* hp, int tile, void* stream);
 extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad, int bn, int transposed);
 extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w, int bn,
                                         int transposed, void* stream);

@@ -1,3 +1,8 @@
+// EXPERIMENT / A-B REFERENCE, not part of libctsi.so (compile-checked by `make experiments`): the 32x32x16-MFMA form of the
+// 512-voxel tile, superseded by conv3_halo_k32.hip (+10-12 % on real data), and its opt-in normalise-on-load variant
+// (NIN = true: GroupNorm + SiLU + time bias applied to the staged halo tile in LDS; bit-identical to the separate pass but
+// +0.9 ms per step).  Measurements: profiles/r02_notes.md.
+//
 // 3x3x3 stride-1 convolution, LDS halo tile 4 x 4 x 32 voxels (512 output voxels) x 128 couts, 16-channel chunks.
 //
 // Measured on conv3_halo32_kernel (4x2x32 x 128 couts, 32-channel chunks): the LDS-DMA *instructions* (1 KB per wave
@@ -9,7 +14,7 @@
 // Weight image and swizzles as in conv3_halo_n64.hip ([chunk16][27][cout_pad][16], slot = khalf ^ ((row >> 3) & 1)),
 // 4-deep weight ring with counted vmcnt waits.  The 128 KB output tile goes through LDS in one pass (it reuses the
 // halo + weight buffers; the row-offset table and the column-sum scratch sit behind it).
-#include "conv3_halo_common.h"
+#include "../conv3_halo_common.h"
 #include <stdlib.h>
 
 // Tile shapes: <4,4> = 4 x 4 x 32 = 512 voxels (8 waves) and <6,2> = 6 x 2 x 32 = 384 voxels (6 waves; a 48 x 32 x 32 level

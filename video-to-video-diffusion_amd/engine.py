@@ -332,10 +332,10 @@ class Program:
         `fuse_gn` = (h: Act, slot, gn: nn.GroupNorm, silu: bool): the epilogue stores silu?(gn(h) + conv result)
         instead of the conv result (ctsi_conv_out.gn_x; h may be the output buffer itself).
         `norm_in` = (slot, gn: nn.GroupNorm, silu: bool, tb) with tb = None or (tbias, tbias_off, tbias_stride, step_ptr):
-        x1 is the RAW output of the previous conv and this conv's input is silu?(gn(x1)) + tbias.  Plans that support it
-        (the 512-voxel halo-tile kernel with CTSI_CONV_NORM_IN=1: opt-in, measured slower, see
-        ctsi_conv_plan_supports_norm_in) normalise on load -- the GroupNorm pass never touches HBM; otherwise (the default)
-        the normalisation is emitted as its own in-place pass first.  Either way x1 must not be used raw afterwards."""
+        x1 is the RAW output of the previous conv and this conv's input is silu?(gn(x1)) + tbias: the normalisation is
+        emitted as its own in-place pass first (depth-sharded: its statistics travel with the raw boundary slices in one
+        sync point), so x1 must not be used raw afterwards.  (A normalise-on-load variant of the 512-voxel kernel that
+        applied it to the staged tile in LDS was bit-identical but slower: csrc/experiments/conv3_halo_m512.hip.)"""
         lib = self.lib
         nin_synced = False
         if norm_in is not None and self.shard is not None and x1.halo:
@@ -370,8 +370,8 @@ class Program:
         self.plans.append(plan)
         if cin_w is not None:
             lib.conv_plan_set_weight_cin(plan, cin_w)
-        if norm_in is not None and not (x2 is None and lib.conv_plan_supports_norm_in(plan)):
-            nslot, ngn, nsilu, ntb = norm_in      # unfused: normalise in place, then a plain conv
+        if norm_in is not None:
+            nslot, ngn, nsilu, ntb = norm_in      # normalise in place, then a plain conv
             kw_tb = {} if ntb is None else dict(tbias=ntb[0], tbias_off=ntb[1], tbias_stride=ntb[2], step_ptr=ntb[3])
             self.gn_apply(x1, nslot, ngn, silu_pre=nsilu, out=x1, synced=nin_synced, **kw_tb)
             norm_in = None
@@ -439,22 +439,6 @@ class Program:
             co.c_off = 0
             out_act = out
         co.act = act
-        nin_slot = None
-        if norm_in is not None:
-            nin_slot, ngn, nsilu, ntb = norm_in
-            ngamma = self.dev_f32(lambda: ngn.weight)
-            nbeta = self.dev_f32(lambda: ngn.bias)
-            d_stat = self.shard.depth_total if (self.shard is not None and x1.halo) else x1.d
-            co.nin_gamma, co.nin_beta = ngamma.data_ptr(), nbeta.data_ptr()
-            co.nin_groups, co.nin_eps, co.nin_silu = ngn.num_groups, float(ngn.eps), int(nsilu)
-            co.nin_count = (x1.c // ngn.num_groups) * d_stat * x1.h * x1.w
-            if ntb is not None:
-                co.nin_tbias = ntb[0].data_ptr() + ntb[1] * 4
-                co.nin_tb_stride = ntb[2]
-                co.nin_step_ptr = 0 if ntb[3] is None else ntb[3].data_ptr()
-            if deep and self.shard is not None:
-                co.nin_pad_lo = int(self.shard.rank == 0)
-                co.nin_pad_hi = int(self.shard.rank == self.shard.world - 1)
         if fuse_gn is not None:
             gh, gslot, gmod, gsilu = fuse_gn
             if f32_out is not None or want_stats or (gh.n, gh.c, gh.d, gh.h, gh.w) != (x1.n, cout, out.d, ho, wo):
@@ -478,13 +462,9 @@ class Program:
             co.colsum = prog._colsum.data_ptr() if want_stats else 0
             if gn_slot is not None:
                 co.gn_sums = prog._gn_sums.data_ptr() + gn_slot * 8
-            if nin_slot is not None:
-                co.nin_sums = prog._gn_sums.data_ptr() + nin_slot * 8
             lib.conv_fwd(plan, x1p, x2p, _ptr(holder[0]), bp, C.byref(co), sptr)
 
         kernel = "conv_mfma_%dx%d_m%d%s" % (bm.value, bn.value, mode.value, "t" if (transposed and mode.value == 9) else "")
-        if norm_in is not None:
-            name = name + "+gn_in"
         self._emit(run, name, fl, kernel)
         return out_act, stats
 

@@ -46,9 +46,6 @@ class ConvOut(C.Structure):
         ("colsum", C.c_void_p),
         ("gn_x", C.c_void_p), ("gn_sums", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
         ("gn_groups", C.c_int), ("gn_eps", C.c_float), ("gn_count", C.c_longlong), ("gn_silu", C.c_int),
-        ("nin_sums", C.c_void_p), ("nin_gamma", C.c_void_p), ("nin_beta", C.c_void_p), ("nin_tbias", C.c_void_p),
-        ("nin_step_ptr", C.c_void_p), ("nin_tb_stride", C.c_int), ("nin_groups", C.c_int), ("nin_silu", C.c_int),
-        ("nin_eps", C.c_float), ("nin_count", C.c_longlong), ("nin_pad_lo", C.c_int), ("nin_pad_hi", C.c_int),
     ]
 
 
@@ -86,7 +83,6 @@ SIGNATURES = {
     "ctsi_conv_plan_tiles_per_sample": (_i, [_vp], False),
     "ctsi_conv_plan_cout_pad": (_i, [_vp], False),
     "ctsi_conv_plan_flops": (C.c_double, [_vp], False),
-    "ctsi_conv_plan_supports_norm_in": (_i, [_vp], False),
     "ctsi_conv_plan_config": (_i, [_vp, _ip, _ip, _ip], True),
     "ctsi_conv_plan_pack_weights": (_i, [_vp, _vp, _vp, _vp], True),
     "ctsi_conv_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ConvOut), _vp], True),

@@ -1,6 +1,6 @@
 """Interleaved A/B timing of one conv layer under several plan-selection environments (variants alternate inside one
 process: separate processes drift by several percent with clock / thermal state).
-    python tools/ab_variants.py --cin 512 --cout 512 --dhw 48 16 16 CTSI_CONV_H32W16=0 CTSI_CONV_H32W16=1 CTSI_CONV_H32W16=2
+    python tools/ab_variants.py --cin 512 --cout 512 --dhw 48 16 16 CTSI_CONV_H32W16=1 CTSI_CONV_H32W16=2
     python tools/ab_variants.py --cin 128 --cout 8 --f32 --dhw 48 128 128 CTSI_CONV_NO_HEAD3=1 -
 (a variant is a comma-separated list of NAME=value settings; "-" = no setting)"""
 import argparse, importlib, os, sys

@@ -648,9 +648,10 @@ struct ctsi_conv_plan {
     int fast, dshift;
     int h32_w16;    // halo3 == 2 only: 1 = 4x4x16 tile (two W-lines of 16 per A tile), 2 = 3x4x16 tile, instead of 4x2x32
     int m512_w16;   // halo3 == 7 only: tile of the k32 kernel: 0 = 4x4x32, 2 = 4x8x16, 3 = 3x4x32 (384 voxels)
-    int halo3;  // 1: 3x3x3 halo-tile kernel, 4x4x16 tile; 2: 4x2x32 tile (conv3_halo.hip); 5: 512-voxel tile
-                // (conv3_halo_m512.hip).  3 / 4 were the persistent-block and half-size-block experiments, now under
-                // csrc/experiments/ (measured slower, profiles/r01_notes.md) and no longer built into libctsi.so.
+    int halo3;  // 3x3x3 halo-tile kernels: 2 = conv3_halo32_kernel (conv3_halo.hip: 4x2x32 / 4x4x16 / 3x4x16 tiles), 6 = few-cout
+                // heads (conv3_head.hip), 7 = conv3_halo_k32_kernel (conv3_halo_k32.hip: 512- / 384-voxel tiles, ConvTranspose).
+                // 1 (16x16x32 form of the 4x4x16 tile), 3 / 4 (persistent and half-size blocks) and 5 (32x32x16 form of the
+                // 512-voxel tile) were measured slower and live under csrc/experiments/, outside libctsi.so.
     double flops;
 };
 
@@ -875,11 +876,11 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 pick = 5;
                 p->m512_w16 = 2;
             }
-            {   // 16-wide levels on the 32x32x16-MFMA kernel instead of conv3_halo_kernel's 16x16x32 form: tile 4x4x16 (256
-                // voxels) or 3x4x16 (192 voxels; 3x1 MFMA tiles per wave: 0.95 of the 2x2 form's efficiency) -- whichever
-                // fills the 256 CUs better (48x16x16 x 512 couts: 192 vs 256 blocks)
-                const char* hw = getenv("CTSI_CONV_H32W16");   // "0" | "1" | "2" (tuning aid)
-                if (pick == 1 && !(hw && !strcmp(hw, "0"))) {
+            {   // 16-wide levels: tile 4x4x16 (256 voxels; an A tile of 32 rows = two W-lines of 16) or 3x4x16 (192 voxels; 3x1
+                // MFMA tiles per wave: 0.95 of the 2x2 form's efficiency) of conv3_halo32_kernel -- whichever fills the 256
+                // CUs better (48x16x16 x 512 couts: 192 vs 256 blocks)
+                const char* hw = getenv("CTSI_CONV_H32W16");   // "1" | "2" (tuning / test aid)
+                if (pick == 1) {
                     pick = 2;
                     p->h32_w16 = score(3, 4, 16, 0.95) > score(4, 4, 16, 1.0) ? 2 : 1;
                     if (hw && !strcmp(hw, "1")) p->h32_w16 = 1;
@@ -955,8 +956,6 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
         p->TD = p->h32_w16 == 2 ? 3 : 4; p->TH = p->h32_w16 ? 4 : 2; p->TW = p->h32_w16 ? 16 : 32;
     } else if (p->halo3 == 6) {
         p->TD = 4; p->TH = 2; p->TW = 16;
-    } else if (p->halo3) {
-        p->TD = 4; p->TH = 4; p->TW = 16;
     } else {
         choose_tile(p->BM, p->Dr, p->Hr, p->Wr, &p->TD, &p->TH, &p->TW);
     }
@@ -1156,7 +1155,7 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             return ctsi_conv3_head_launch(&h, p->d.cout <= 8 ? 8 : 16, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
         h.tr = p->d.transposed;
         if (p->halo3 == 7) return ctsi_conv3_halo_k32_launch(&h, p->m512_w16, p->BN, stream);
-        return ctsi_conv3_halo_launch(&h, p->halo3 == 2 ? (p->h32_w16 == 2 ? 4 : (p->h32_w16 ? 3 : 1)) : 0, stream);
+        return ctsi_conv3_halo_launch(&h, p->h32_w16 == 2 ? 4 : (p->h32_w16 ? 3 : 1), stream);
     }
     CTSI_CHECK_ARG(!p->halo3, "ctsi_conv_fwd: the 3x3x3 halo-tile plan supports bf16 NDHWC output without activation");
     ConvKParams k;

@@ -577,12 +577,13 @@ static int wg_geometry(const ctsi_wgrad_desc* d, WgradGeom* g) {
     // byte of LDS fill, 8-wave blocks, one per CU).  Measured against the one-tap kernel (profiles/r02_notes.md): K-steps of
     // 64 voxels + software-pipelined fragments + staggered DMA issue bring it from 10-20 % behind to par on the config-3
     // shapes (653 / 715 / 606 / 767 vs 656 / 747 / 691 / 766 TFLOP/s) and ahead on long single-tile layers (128->128 @48x128^2:
-    // 830-867 vs 766-790): it is selected for those; CTSI_WGRAD_S1 = "0" | "32" | "64" overrides (off / K-step).
+    // 830-867 vs 766-790): it is selected for those; CTSI_WGRAD_S1 = "0" | "64" overrides (off / on wherever it applies).
+    // (Its 32-voxel K-step form, 10-20 % behind, is no longer instantiated.)
     const char* s1 = getenv("CTSI_WGRAD_S1");
     const bool s1_ok = d->sh == 1 && d->sw == 1 && d->dr == d->dg && d->hr == d->hg && d->wr == d->wg && (d->kw == 3 || d->kw == 1);
-    if (s1_ok && s1 && (atoi(s1) == 32 || atoi(s1) == 64 || atoi(s1) == 1)) {
+    if (s1_ok && s1 && atoi(s1) == 64) {
         g->tg = d->kw;
-        g->bk = atoi(s1) == 64 ? 64 : 32;
+        g->bk = 64;
     } else if (s1_ok && !s1 && d->kw == 3 && g->tiles_r * g->tiles_g == 1 && g->V >= 600000) {
         g->tg = 3;
         g->bk = 64;
@@ -638,15 +639,12 @@ extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* g
     const long long blocks = (long long)(g.tg ? g.T / g.tg : g.T) * g.tiles_r * g.tiles_g * g.S;
     CTSI_CHECK_ARG(blocks < (1ll << 31), "ctsi_wgrad: grid too large");
     if (g.tg) {
-        auto k = g.tg == 3 ? (g.bk == 64 ? conv_wgrad_s1_kernel<3, 64> : conv_wgrad_s1_kernel<3, 32>)
-                           : (g.bk == 64 ? conv_wgrad_s1_kernel<1, 64> : conv_wgrad_s1_kernel<1, 32>);
-        const int lds = g.bk == 64 ? wg3::Cfg<64>::LDS_BYTES : wg3::Cfg<32>::LDS_BYTES;
+        auto k = g.tg == 3 ? conv_wgrad_s1_kernel<3, 64> : conv_wgrad_s1_kernel<1, 64>;
+        const int lds = wg3::Cfg<64>::LDS_BYTES;
         static bool attr_done = false;
         if (!attr_done) {
             hipFuncSetAttribute((const void*)conv_wgrad_s1_kernel<3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)conv_wgrad_s1_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)conv_wgrad_s1_kernel<3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)conv_wgrad_s1_kernel<1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(wg3::NTH), lds, (hipStream_t)stream, p);

@@ -5,7 +5,9 @@ profiles/<out>.json: per kernel, the share of SIMD cycles with the MFMA pipe bus
         --output-format csv -d gpurun_out/pmc_mfma -o mfma -- python3 tools/profile_ops.py --repeats 1
     python tools/pmc_mfma.py gpurun_out/pmc_mfma/mfma_counter_collection.csv profiles/r02_pmc_mfma_busy.json <commit>
 
-GRBM_GUI_ACTIVE is summed over the 8 XCDs: mfma_busy_frac = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024 SIMDs)."""
+GRBM_GUI_ACTIVE is summed over the 8 XCDs: mfma_busy_frac = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024 SIMDs); the clock the part held
+during a dispatch = GUI_ACTIVE / 8 / (End_Timestamp - Start_Timestamp) (MI355X_MICROARCH.md, DVFS give-back: reads high on
+dispatches shorter than ~0.3 ms; profiled passes run a few percent below un-profiled ones)."""
 import csv
 import json
 import re
@@ -21,6 +23,10 @@ with open(path) as f:
         c = a.setdefault(row["Counter_Name"], [0, 0.0])
         c[0] += 1
         c[1] += float(row["Counter_Value"])
+        if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and row.get("End_Timestamp"):
+            t = a.setdefault("_ns", [0, 0.0])
+            t[0] += 1
+            t[1] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
 res = {"commit": commit, "method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE "
                                    "over tools/profile_ops.py --repeats 1 (eager U-Net evaluations @ latent (1,8,48,128,128))",
        "kernels": {}}
@@ -32,8 +38,12 @@ for name, a in agg.items():
         continue
     conf = a.get("SQ_LDS_BANK_CONFLICT", [0, 0.0])[1]
     act = a.get("SQ_LDS_IDX_ACTIVE", [0, 1.0])[1]
+    ns = a.get("_ns", [0, 0.0])[1]
     res["kernels"][name] = {"launches": a["GRBM_GUI_ACTIVE"][0], "mfma_busy_frac": busy / (gui / 8.0 * 1024.0),
-                            "lds_bank_conflict_frac": conf / act if act > 0 else None}
+                            "lds_bank_conflict_frac": conf / act if act > 0 else None,
+                            "avg_dispatch_us": ns / a["GRBM_GUI_ACTIVE"][0] / 1e3 if ns > 0 else None,
+                            "clock_ghz": gui / 8.0 / ns if ns > 0 else None}
 json.dump(res, open(out, "w"), indent=1)
 for k, v in sorted(res["kernels"].items(), key=lambda kv: -kv[1]["mfma_busy_frac"]):
-    print(f"{k[:70]:70s} launches {v['launches']:4d}  MFMA busy {100 * v['mfma_busy_frac']:5.1f} %")
+    print(f"{k[:70]:70s} launches {v['launches']:4d}  MFMA busy {100 * v['mfma_busy_frac']:5.1f} %  "
+          f"clock {v['clock_ghz'] or 0:.2f} GHz  {v['avg_dispatch_us'] or 0:7.1f} us")

@@ -1,6 +1,7 @@
 """CPU: host-side mirror of the reference interface — import surface, state-dict layout, config
 quirks, error behaviour, and that the product path refuses to run without the HIP device."""
 import importlib
+import os
 import re
 
 import numpy as np
@@ -251,3 +252,19 @@ def test_dataset_tensor_contract(tmp_path, pkg):
         DC.unpack_batch({"input": torch.zeros(1, 1, 2, 30, 24), "target": torch.zeros(1, 1, 12, 30, 24)})
     with pytest.raises(ValueError, match="needs 'input' and 'target'"):
         DC.unpack_batch({"category": ["x"]})
+
+
+def test_integration_doc_struct_matches_the_abi():
+    """INTEGRATION.md shows the ctypes mirror of ctsi_conv_out a maintainer would paste next to the reference's modules:
+    it must list exactly the fields (and order) of the binding the package itself uses."""
+    import importlib
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    L = importlib.import_module("video-to-video-diffusion_amd.lib")
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class ConvOut"):doc.index("def _check")]
+    assert re.findall(r'\("(\w+)", C\.c_\w+\)', stub) == [f[0] for f in L.ConvOut._fields_]
+    hdr = open(os.path.join(root, "include", "ctsi.h")).read()
+    body = hdr[hdr.index("typedef struct ctsi_conv_out"):hdr.index("} ctsi_conv_out;")]
+    for name, _ in L.ConvOut._fields_:
+        assert re.search(r"\b%s\b" % name, body), name

@@ -103,6 +103,9 @@ typedef struct ctsi_conv_out {
     float gn_eps;
     long long gn_count;      /* elements per (sample, group) the statistics were taken over                       */
     int gn_silu;             /* 1: SiLU after the add                                                             */
+    /* split-K plans (ctsi_conv_plan_workspace_bytes() > 0): device scratch of that size that belongs to THIS layer; zero it
+     * once before the first launch (it holds the hand-off tickets), the kernel leaves it ready for the next launch      */
+    void* workspace;
 } ctsi_conv_out;
 
 int ctsi_conv_plan_create(ctsi_conv_plan** plan, const ctsi_conv_desc* desc);
@@ -118,6 +121,8 @@ size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* plan);
 int ctsi_conv_plan_tiles(const ctsi_conv_plan* plan);
 int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* plan);
 int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* plan);
+/* bytes of ctsi_conv_out.workspace this plan needs (0 for most plans) */
+size_t ctsi_conv_plan_workspace_bytes(const ctsi_conv_plan* plan);
 /* algorithmic FLOPs (2*MAC, dense direct convolution) of one forward of this layer */
 double ctsi_conv_plan_flops(const ctsi_conv_plan* plan);
 /* which kernel variant the plan launches: MFMA tile (bm x bn) and staging mode

@@ -121,7 +121,7 @@ HALO3_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["16h", "16h3", "32", "16k", "32k", "32k3"])
+@pytest.mark.parametrize("tile", ["16h", "16h3", "32", "16k", "32k", "32k3", "16k3", "16k3s"])
 @pytest.mark.parametrize("name,c1,c2,cout,dims", HALO3_CASES, ids=[c[0] for c in HALO3_CASES])
 def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     """The LDS halo-tile 3x3x3 kernel (conv3_halo.hip) on aligned, ragged, multi-tile and two-source inputs;
@@ -141,6 +141,8 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     monkeypatch.setenv("CTSI_CONV_HALO_TILE", "32" if tile == "16k" else tile[:2])   # ("16h3": the 192-voxel tile)
     monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile == "16k" else "0")
     monkeypatch.setenv("CTSI_CONV_K32_384", "1" if tile == "32k3" else "0")
+    # "16k3": the 3x8x16 = 384-voxel tile; "16k3s": with 2-way split-K (Cin % 128 == 0 cases; the others fall back)
+    monkeypatch.setenv("CTSI_CONV_K32_SPLITK", {"16k3": "plain", "16k3s": "1"}.get(tile, "0"))
     if tile in ("16h", "16h3"):
         monkeypatch.setenv("CTSI_CONV_H32W16", {"16h": "1", "16h3": "2"}[tile])    # 4x4x16 / 3x4x16 tiles
     monkeypatch.setenv("CTSI_CONV_M512", "1" if tile in ("32k", "16k", "32k3") else "0")
@@ -153,6 +155,49 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     monkeypatch.setenv("CTSI_CONV_NO_HALO3", "1")
     y2, _ = G.run_conv(x1, x2, wt, b)
     assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
+def test_split_k_conv_is_bit_stable_and_matches(G, monkeypatch):
+    """2-way split-K form of the k32 kernel (conv3_halo_k32_kernel<..., SK>): the benchmark's 16-wide level shape class
+    (few voxels, 512 input channels, several n-tiles, ragged edges, batch 2) -- same result whichever half finishes first
+    (a + b = b + a): repeated launches are bit-identical, the workspace is left ready for the next launch, and the plan
+    reports the workspace it needs."""
+    import ctypes as C
+    import importlib
+    E = importlib.import_module("video-to-video-diffusion_amd.engine")
+    n, cin, cout, d, h, w = 2, 512, 256, 7, 11, 16
+    x = bf16_round(formula_input((n, cin, d, h, w), 71))
+    wt = bf16_round(_w((cout, cin, 3, 3, 3), 72))
+    b = formula_input((cout,), 73) * 0.1
+    ref = F.conv3d(x, wt, b, padding=1)
+    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
+    monkeypatch.setenv("CTSI_CONV_K32_SPLITK", "1")
+    lib, plan, mode, bm = G.ctx().lib, C.c_void_p(), C.c_int(), C.c_int()
+    lib.conv_plan_create(C.byref(plan), C.byref(E.ConvDesc(0, 3, 3, 3, 1, 1, 1, 1, 1, n, cin, 0, cout, d, h, w, 0)))
+    lib.conv_plan_config(plan, C.byref(bm), None, C.byref(mode))
+    tiles = lib.conv_plan_tiles(plan) * (lib.conv_plan_cout_pad(plan) // 128)
+    assert (bm.value, mode.value) == (384, 9) and lib.conv_plan_workspace_bytes(plan) >= tiles * 96 * 512 * 4
+    lib.conv_plan_destroy(plan)
+    c = G.ctx()
+    with c.scope():
+        prog = E.Program(c)
+        a = G.to_act(prog, x)
+        prog.zero_gn_op()
+        y, st = prog.conv("c", lambda: wt, lambda: b, a, None, cout=cout, want_stats=True)
+        slot = prog.gn_finalize(y, 8, st)
+        prog.finalize_layout()
+        outs = []
+        for _ in range(4):
+            prog.run()
+            outs.append((G.from_act(prog, y).clone(), prog._gn_sums[slot:slot + n * 16].clone()))
+    torch.cuda.synchronize()
+    assert rel_l2(outs[0][0].cpu(), ref) < CONV_TOL
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+    rg = ref.reshape(n, 8, -1).double()
+    sums = outs[0][1].reshape(n, 8, 2).cpu()
+    assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+    assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
 
 
 CONVT_CASES = [

@@ -75,7 +75,16 @@ __device__ __forceinline__ void hk_wait_vm(int allowed) {   // wave-uniform `all
 // input rows {h, h - 1} for py = 0, {2, 0} at {h, h + 1} for py = 1; same along w; i_d = o_d + 1 - k_d), i.e. the same halo
 // tile as the 3x3x3 conv with 12 entries per chunk instead of 27.  One block = one (input tile, class, n-tile); the four
 // classes of a tile are neighbours in the grid (they share the halo in L2).
-template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false>
+//
+// SK = true: 2-way split-K.  Levels with few voxels and many channels (48 x 16 x 16 x 512 -> 512: 32 tiles of 384 voxels x 4
+// n-tiles = 128 blocks for 256 CUs) run every (tile, n-tile) as TWO blocks that each walk half of the input-channel chunks.
+// The block that finishes first parks its fp32 accumulators in a workspace ([tile][register][512 threads]: coalesced, the
+// partner has the same register <-> output mapping) and leaves; the second adds them to its own and runs the epilogue.  a + b
+// = b + a in fp32, so the result does not depend on which block comes first: bit-stable without a second pass.  Hand-off per
+// MI355X_MICROARCH.md (per-XCD L2s are not coherent): the producer's stores, __threadfence, workgroup barrier, agent-scope
+// release of a flag; the consumer's agent-scope acquire by one lane, workgroup barrier, plain loads.  The consumer waits only
+// for a block that has already taken its ticket, i.e. one that is in its epilogue: no deadlock; the spin is bounded anyway.
+template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false, bool SK = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, 512)))
 conv3_halo_k32_kernel(const Conv3HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -95,7 +104,9 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int bid = xcd_remap_h(blockIdx.x, gridDim.x);
+    int bid = xcd_remap_h(blockIdx.x, gridDim.x);
+    const int khalf = SK ? (bid & 1) : 0;                    // the two halves of a tile are neighbours in the grid
+    if (SK) bid >>= 1;
     int mt, nt, cls = 0;
     if (TR) {
         // siblings = the 4 ntiles_n (class, n-tile) blocks of one input tile: they share the halo, each streams its own weight
@@ -115,6 +126,8 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     }
     const int py = cls >> 1, px = cls & 1;
     const int n0 = nt * BN;
+    const int nchunks = SK ? p.nchunks / 2 : p.nchunks;      // chunks this block walks, starting at chunk cbase
+    const int cbase = khalf * nchunks;
     const int nb = mt / p.tps;
     int r0 = mt - nb * p.tps;
     const int tD = r0 / (p.tilesH * p.tilesW);
@@ -143,7 +156,9 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const v4i_t rs2 = h3_make_rsrc(reinterpret_cast<const char*>(p.x2) + basevox * p.C2 * 2, 0x7fffffffu);
     // (TR: one packed image per class, each padded to whole steps)
     const long long w_class = (long long)((p.nchunks * TAPS + STEP_TAPS - 1) / STEP_TAPS) * STEP_TAPS * p.CoutPad * 32;
-    const v4i_t rsw = h3_make_rsrc(reinterpret_cast<const char*>(p.w) + cls * w_class + (long long)n0 * 32, 0x7fffffffu);
+    // (SK: the second half starts at entry TAPS * cbase of the packed stream: a whole number of steps, checked on the host)
+    const v4i_t rsw = h3_make_rsrc(reinterpret_cast<const char*>(p.w) + cls * w_class + (long long)n0 * 32 +
+                                       (long long)cbase * TAPS * p.CoutPad * 32, 0x7fffffffu);
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;
 
     // halo DMA: piece j = wave + NWAVE * i covers halo voxels 32 j .. 32 j + 31; lane -> voxel 32 j + lane / 2, 16-byte half lane & 1
@@ -159,14 +174,14 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         hrel[i] = ok ? ((gd - dlo) * p.Hi + gh) * p.Wi + gw : -1;
     }
     const unsigned hq16 = (unsigned)((lane & 1) * 16);
-    const int C1 = p.C1, C2 = p.C2, CoutPad = p.CoutPad, nchunks = p.nchunks;
+    const int C1 = p.C1, C2 = p.C2, CoutPad = p.CoutPad;
     const int Q = nchunks * TAPS;                            // (chunk, tap) entries
     const int S = (Q + STEP_TAPS - 1) / STEP_TAPS;           // steps (the packed image is zero-padded to whole steps)
 
     auto issue_halo = [&](int cc, int i) -> int {
         const int j = wave + NWAVE * i;
         if (j >= HALO_INSTR) return 0;
-        const int ch0 = cc * 16;
+        const int ch0 = (cbase + cc) * 16;
         const bool second = ch0 >= C1;
         const unsigned cbytes = (unsigned)((second ? C2 : C1) * 2);
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? ch0 - C1 : ch0) * 2);
@@ -384,6 +399,52 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     // ---- epilogue: bias, GroupNorm column sums, the 512 x 128 bf16 tile through LDS (128 KB), 16-byte row stores -----
     // accumulator (i, j)[q]: row 16 i + 4 kg + q of the wave's 64, cout 16 j + r16
     if (p.dbg & 8) return;
+    if (SK) {
+        const int tile = mt * p.ntiles_n + nt;
+        constexpr int NREG = MA * NJ * 4;
+        float* wsl = p.sk_ws + (size_t)tile * NREG * NTH + tid;
+        int* s_role = reinterpret_cast<int*>(s_cs);          // (s_cs is first written after the barriers below)
+        if (tid == 0) *s_role = __hip_atomic_fetch_add(p.sk_sync + 2 * tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int role = *s_role;
+        __syncthreads();
+        // Hand-off without cache maintenance (MI355X_MICROARCH.md, second valid form): EVERY store and load of the handed-off
+        // bytes is an agent-scope (sc1) access, drained before the flag is raised; a release / acquire pair would write back
+        // and invalidate the XCD's whole L2 -- 128 times per launch, under the weight streams of the blocks still computing.
+        if (role == 0) {                                     // first to finish: park the partial sums and leave
+#pragma unroll
+            for (int i = 0; i < MA; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        __hip_atomic_store(wsl + (size_t)((i * NJ + j) * 4 + q) * NTH, acc[i][j][q], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(p.sk_sync + 2 * tile + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(p.sk_sync + 2 * tile + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && spins < (1 << 22)) {
+                __builtin_amdgcn_s_sleep(4);
+                ++spins;
+            }
+            // ready for the next launch on this stream
+            __hip_atomic_store(p.sk_sync + 2 * tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.sk_sync + 2 * tile + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MA; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[i][j][q] += __hip_atomic_load(wsl + (size_t)((i * NJ + j) * 4 + q) * NTH, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+    }
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16
     const bool want_sums = p.colsum != nullptr;
     unsigned vbits = 0;
@@ -505,22 +566,35 @@ extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, 
     return CTSI_OK;
 }
 
-template <int TD, int TH, int TW, int BN, int UPS, bool TR>
+template <int TD, int TH, int TW, int BN, int UPS, bool TR, bool SK = false>
 static void hk_launch(const Conv3HaloParams* hp, hipStream_t stream) {
     using Cfg = HkCfg<TD, TH, TW, BN, UPS>;
-    auto k = conv3_halo_k32_kernel<TD, TH, TW, BN, UPS, TR>;
+    auto k = conv3_halo_k32_kernel<TD, TH, TW, BN, UPS, TR, SK>;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3((TR ? 4 : 1) * hp->mtiles * hp->ntiles_n), dim3(Cfg::NTH), Cfg::LDS_BYTES, stream, *hp);
+    hipLaunchKernelGGL(k, dim3((TR ? 4 : 1) * (SK ? 2 : 1) * hp->mtiles * hp->ntiles_n), dim3(Cfg::NTH), Cfg::LDS_BYTES, stream,
+                       *hp);
 }
 
-extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16, 3: 3x4x32 */, int bn,
+extern "C" size_t ctsi_conv3_halo_k32_splitk_bytes(int tiles) {   // [2 ints per tile: ticket, flag | pad to 256 B][partials]
+    const size_t sync = ((size_t)tiles * 8 + 255) / 256 * 256;
+    return sync + (size_t)tiles * (3 * 8 * 4) * 512 * sizeof(float);
+}
+
+extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16, 3: 3x4x32, 5: 3x8x16 */, int bn,
                                           void* stream) {
-    CTSI_CHECK_ARG(bn == 128 && (tile != 3 || !hp->tr), "ctsi_conv3_halo_k32_launch: bad BN %d / tile %d", bn, tile);
-    if (tile == 3) {
+    CTSI_CHECK_ARG(bn == 128 && ((tile != 3 && tile != 5) || !hp->tr), "ctsi_conv3_halo_k32_launch: bad BN %d / tile %d", bn, tile);
+    if (tile == 5) {          // 3x8x16 = 384 voxels for 16-wide levels, plain or 2-way split-K
+        if (hp->ksplit == 2) {
+            CTSI_CHECK_ARG(hp->sk_ws && hp->sk_sync && hp->nchunks % 8 == 0, "ctsi_conv3_halo_k32_launch: split-K needs its workspace");
+            hk_launch<3, 8, 16, 128, 2, false, true>(hp, (hipStream_t)stream);
+        } else {
+            hk_launch<3, 8, 16, 128, 2, false, false>(hp, (hipStream_t)stream);
+        }
+    } else if (tile == 3) {
         hk_launch<3, 4, 32, 128, 2, false>(hp, (hipStream_t)stream);
     } else if (hp->tr) {
         if (tile == 2)

@@ -647,7 +647,8 @@ struct ctsi_conv_plan {
     int tap_margin[4], ad_min[4];
     int fast, dshift;
     int h32_w16;    // halo3 == 2 only: 1 = 4x4x16 tile (two W-lines of 16 per A tile), 2 = 3x4x16 tile, instead of 4x2x32
-    int m512_w16;   // halo3 == 7 only: tile of the k32 kernel: 0 = 4x4x32, 2 = 4x8x16, 3 = 3x4x32 (384 voxels)
+    int m512_w16;   // halo3 == 7 only: tile of the k32 kernel: 0 = 4x4x32, 2 = 4x8x16, 3 = 3x4x32, 5 = 3x8x16 (384 voxels)
+    int ksplit;     // halo3 == 7, tile 5: 2 = two blocks per (tile, n-tile), each half of the input-channel chunks (needs a workspace)
     int halo3;  // 3x3x3 halo-tile kernels: 2 = conv3_halo32_kernel (conv3_halo.hip: 4x2x32 / 4x4x16 / 3x4x16 tiles), 6 = few-cout
                 // heads (conv3_head.hip), 7 = conv3_halo_k32_kernel (conv3_halo_k32.hip: 512- / 384-voxel tiles, ConvTranspose).
                 // 1 (16x16x32 form of the 4x4x16 tile), 3 / 4 (persistent and half-size blocks) and 5 (32x32x16 form of the
@@ -912,6 +913,28 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                     p->h32_w16 = 0;
                     p->m512_w16 = 3;
                 }
+                // 16-wide levels with deep K and few voxels (48x16x16, 512 -> 512: 192 / 256 / 128 blocks with 512- / 192- / 384-
+                // voxel tiles): 3x8x16 = 384 voxels with 2-way split-K = 256 blocks of half the channel chunks each (one round,
+                // half the weight bytes per block).  Measured 0.141 ms per half-K block against 0.18 ms for the 192-voxel tile.
+                const char* sk = getenv("CTSI_CONV_K32_SPLITK");   // "0" | "1" | "plain" (tuning / test aid)
+                auto score_sk = [&]() {
+                    const long long t = (long long)d.n * ceil_div(p->Dr, 3) * ceil_div(p->Hr, 8) * ceil_div(p->Wr, 16);
+                    const long long b = 2 * t * ceil_div(d.cout, 128);
+                    const double useful = (double)rows * d.n / ((double)t * 384);
+                    return useful * (double)b / (double)(((b + 255) / 256) * 256) * 1.1;
+                };
+                const bool sk_ok = p->Cin % 128 == 0 && d.c1 % 16 == 0 && d.c2 % 16 == 0;
+                const double cur2 = use384 ? score(3, 4, 32, 1.1) : cur;
+                bool use_sk = sk_ok && score_sk() > cur2;
+                if (sk && !strcmp(sk, "0")) use_sk = false;
+                if (sk && !strcmp(sk, "1") && sk_ok) use_sk = true;
+                if (use_sk || (sk && !strcmp(sk, "plain"))) {
+                    p->halo3 = 7;
+                    p->BM = 384;
+                    p->h32_w16 = 0;
+                    p->m512_w16 = 5;
+                    p->ksplit = use_sk ? 2 : 1;
+                }
             }
         }
         // ConvTranspose3d (3,4,4) / (1,2,2) on the k32 kernel: each parity class is a 12-tap convolution on the input grid with
@@ -946,7 +969,9 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
-    if (p->halo3 == 7 && p->m512_w16 == 3) {
+    if (p->halo3 == 7 && p->m512_w16 == 5) {
+        p->TD = 3; p->TH = 8; p->TW = 16;
+    } else if (p->halo3 == 7 && p->m512_w16 == 3) {
         p->TD = 3; p->TH = 4; p->TW = 32;
     } else if (p->halo3 == 7 && p->m512_w16 == 2) {
         p->TD = 4; p->TH = 8; p->TW = 16;
@@ -1012,6 +1037,11 @@ extern "C" int ctsi_conv_plan_tiles(const ctsi_conv_plan* p) { return p ? p->ncl
 extern "C" int ctsi_conv_plan_tiles_per_sample(const ctsi_conv_plan* p) { return p ? p->tps : 0; }
 extern "C" int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* p) { return p ? p->CoutPad : 0; }
 extern "C" double ctsi_conv_plan_flops(const ctsi_conv_plan* p) { return p ? p->flops : 0.0; }
+extern "C" size_t ctsi_conv_plan_workspace_bytes(const ctsi_conv_plan* p) {
+    // split-K plans: tickets / flags + fp32 partial accumulators (ctsi_conv_out.workspace; zero the first 8 * tiles bytes once)
+    if (!p || p->ksplit != 2) return 0;
+    return ctsi_conv3_halo_k32_splitk_bytes(p->mtiles * p->ntiles_n);
+}
 extern "C" int ctsi_conv_plan_config(const ctsi_conv_plan* p, int* bm, int* bn, int* mode) {
     CTSI_CHECK_ARG(p, "ctsi_conv_plan_config: null plan");
     if (bm) *bm = p->BM;
@@ -1154,6 +1184,13 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         if (p->halo3 == 6)
             return ctsi_conv3_head_launch(&h, p->d.cout <= 8 ? 8 : 16, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
         h.tr = p->d.transposed;
+        if (p->halo3 == 7 && p->ksplit == 2) {
+            CTSI_CHECK_ARG(o->workspace, "ctsi_conv_fwd: this plan needs ctsi_conv_out.workspace (ctsi_conv_plan_workspace_bytes)");
+            const int tiles = p->mtiles * p->ntiles_n;
+            h.ksplit = 2;
+            h.sk_sync = (int*)o->workspace;
+            h.sk_ws = (float*)((char*)o->workspace + ((size_t)tiles * 8 + 255) / 256 * 256);
+        }
         if (p->halo3 == 7) return ctsi_conv3_halo_k32_launch(&h, p->m512_w16, p->BN, stream);
         return ctsi_conv3_halo_launch(&h, p->h32_w16 == 2 ? 4 : (p->h32_w16 ? 3 : 1), stream);
     }

@@ -102,6 +102,9 @@ struct Conv3HaloParams {
     int nin_pad_lo, nin_pad_hi;   // depth-sharded input: the first / last halo slice is a volume end (reads as zero padding)
     float nin_eps;
     double nin_count;
+    int ksplit;           // conv3_halo_k32_kernel<SK>: 2 = two blocks per (tile, n-tile), each half of the chunks
+    float* sk_ws;         //   fp32 partial accumulators [tile][register][512]
+    int* sk_sync;         //   [tile][2]: ticket, ready flag (zero before the first launch; the kernel resets them)
     int tr;               // conv3_halo_k32_kernel: ConvTranspose3d (3,4,4) / (1,2,2): Do/Ho/Wo are the OUTPUT dims, tiles walk the input grid
 };
 
@@ -113,5 +116,6 @@ extern "C" int ctsi_conv3_head_launch(const Conv3HaloParams* hp, int rows, int o
 extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad, int bn, int transposed);
 extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w, int bn,
                                         int transposed, void* stream);
+extern "C" size_t ctsi_conv3_halo_k32_splitk_bytes(int tiles);
 extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile, int bn, void* stream);
 

@@ -264,6 +264,12 @@ class Program:
     def release(self, a: Act):
         self.pool.put(a.t)
 
+    def _conv_workspace(self, plan) -> int:
+        """Device scratch of a split-K conv plan (ctsi_conv_plan_workspace_bytes): one zero-initialised buffer per layer, kept
+        for the program's lifetime (the kernel leaves its hand-off tickets reset after every launch)."""
+        nbytes = self.lib.conv_plan_workspace_bytes(plan)
+        return self.persistent((nbytes,), torch.uint8, zero=True).data_ptr() if nbytes else 0
+
     def persistent(self, shape, dtype, zero=False) -> torch.Tensor:
         t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.ctx.device)
         self.keep.append(t)
@@ -424,6 +430,7 @@ class Program:
             stats = dict(tps=lib.conv_plan_tiles_per_sample(plan), cpad=cpad,
                          nclass=4 if transposed else 1)
         co = ConvOut()
+        co.workspace = self._conv_workspace(plan)
         if f32_out is not None:
             co.y = f32_out.data_ptr()
             co.mode = 1
@@ -549,6 +556,7 @@ class Program:
             self.flops += fl
             self.conv_flops.append((name + "." + tag, fl))
             co = ConvOut()
+            co.workspace = self._conv_workspace(plan)
             co.y, co.mode, co.cout_stride, co.c_off = py, 0, cout, 0
             self.keep.append(co)
             off = col_off

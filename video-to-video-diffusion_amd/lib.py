@@ -46,6 +46,7 @@ class ConvOut(C.Structure):
         ("colsum", C.c_void_p),
         ("gn_x", C.c_void_p), ("gn_sums", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
         ("gn_groups", C.c_int), ("gn_eps", C.c_float), ("gn_count", C.c_longlong), ("gn_silu", C.c_int),
+        ("workspace", C.c_void_p),
     ]
 
 
@@ -79,6 +80,7 @@ SIGNATURES = {
     "ctsi_conv_plan_destroy": (None, [_vp], False),
     "ctsi_conv_plan_out_dims": (_i, [_vp, _ip, _ip, _ip], True),
     "ctsi_conv_plan_weight_bytes": (_sz, [_vp], False),
+    "ctsi_conv_plan_workspace_bytes": (_sz, [_vp], False),
     "ctsi_conv_plan_tiles": (_i, [_vp], False),
     "ctsi_conv_plan_tiles_per_sample": (_i, [_vp], False),
     "ctsi_conv_plan_cout_pad": (_i, [_vp], False),

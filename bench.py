@@ -354,7 +354,11 @@ def main():
             traffic, traffic_source = None, None
             try:
                 pj = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_FILE)))
-                key = dom_name.split(" ")[0]
+                # the profile lists template instantiations: the bench's variant key names the tile (512x128 = <4, 4, 32, ...>)
+                inst = {"conv_mfma_512x128_m9": "conv3_halo_k32_kernel<4, 4, 32, 128, 2, false",
+                        "conv_mfma_512x128_m9t": "conv3_halo_k32_kernel<4, 4, 32, 128, 2, true",
+                        "conv_mfma_384x128_m9": "conv3_halo_k32_kernel<3, 4, 32, 128, 2, false"}
+                key = inst.get(dom_key, dom_name.split(" ")[0])
                 ent = next(v for k_, v in pj["kernels"].items() if k_.startswith(key))
                 traffic = ent["hbm_bytes_per_launch"]
                 traffic_source = {"file": PMC_TRAFFIC_FILE, "commit": pj.get("commit"), "method": pj.get("method")}

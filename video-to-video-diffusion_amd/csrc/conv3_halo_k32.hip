@@ -586,8 +586,12 @@ extern "C" size_t ctsi_conv3_halo_k32_splitk_bytes(int tiles) {   // [2 ints per
 
 extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16, 3: 3x4x32, 5: 3x8x16 */, int bn,
                                           void* stream) {
-    CTSI_CHECK_ARG(bn == 128 && ((tile != 3 && tile != 5) || !hp->tr), "ctsi_conv3_halo_k32_launch: bad BN %d / tile %d", bn, tile);
-    if (tile == 5) {          // 3x8x16 = 384 voxels for 16-wide levels, plain or 2-way split-K
+    CTSI_CHECK_ARG(bn == 128 && (tile == 0 || tile == 2 || tile == 3 || tile == 5), "ctsi_conv3_halo_k32_launch: bad BN %d / tile %d", bn, tile);
+    if (hp->tr && tile == 5) {
+        hk_launch<3, 8, 16, 128, 2, true>(hp, (hipStream_t)stream);
+    } else if (hp->tr && tile == 3) {
+        hk_launch<3, 4, 32, 128, 2, true>(hp, (hipStream_t)stream);
+    } else if (tile == 5) {          // 3x8x16 = 384 voxels for 16-wide levels, plain or 2-way split-K
         if (hp->ksplit == 2) {
             CTSI_CHECK_ARG(hp->sk_ws && hp->sk_sync && hp->nchunks % 8 == 0, "ctsi_conv3_halo_k32_launch: split-K needs its workspace");
             hk_launch<3, 8, 16, 128, 2, false, true>(hp, (hipStream_t)stream);

@@ -941,21 +941,36 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
         // the 3x3x3 conv's halo tile (conv3_halo_k32.hip, TR = true); CTSI_CONV_K32T=0 keeps the gather kernel (A/B timing)
         if (d.transposed && d.c2 == 0 && d.c1 % 16 == 0 && d.cout >= 64 && d.cout % 8 == 0 && p->CinW == p->Cin &&
             extent < 2.0e9) {
-            auto useful = [&](int td, int th, int tw) {
-                const long long t = (long long)ceil_div(p->Dr, td) * ceil_div(p->Hr, th) * ceil_div(p->Wr, tw);
-                return (double)rows / ((double)t * td * th * tw);
-            };
-            const double u32 = useful(4, 4, 32), u16 = useful(4, 8, 16);
+            // tile: useful fraction of the tile rows x fill of the 256 CUs (4 classes x n-tiles blocks per input tile) x relative
+            // efficiency (384-voxel tiles 0.96)
+            struct { int td, th, tw, code; double eff; } cand[4] = {{4, 4, 32, 0, 1.0}, {4, 8, 16, 2, 1.0}, {3, 4, 32, 3, 0.96},
+                                                                    {3, 8, 16, 5, 0.96}};
+            double best = -1.0, best_useful = 0.0;
+            int best_code = 0;
+            for (auto& c : cand) {
+                const long long t = (long long)d.n * ceil_div(p->Dr, c.td) * ceil_div(p->Hr, c.th) * ceil_div(p->Wr, c.tw);
+                const long long b = t * 4 * ceil_div(d.cout, 128);
+                const double useful = (double)rows * d.n / ((double)t * c.td * c.th * c.tw);
+                const double sc = useful * (double)b / (double)(((b + 255) / 256) * 256) * c.eff;
+                if (sc > best) {
+                    best = sc;
+                    best_code = c.code;
+                    best_useful = useful;
+                }
+            }
             const char* kt = getenv("CTSI_CONV_K32T");
             const bool force = getenv("CTSI_CONV_FORCE_HALO3") != nullptr;
-            if ((u32 >= 0.7 || u16 >= 0.7 || force) && !(kt && !strcmp(kt, "0")) && !getenv("CTSI_CONV_NO_HALO3")) {
+            if ((best_useful >= 0.7 || force) && !(kt && !strcmp(kt, "0")) && !getenv("CTSI_CONV_NO_HALO3")) {
                 p->halo3 = 7;
-                p->BM = 512;
                 p->BN = 128;
-                p->m512_w16 = u16 > u32 ? 2 : 0;
-                const char* w16 = getenv("CTSI_CONV_M512W16");    // "0" | "1" (tuning / test aid)
+                p->m512_w16 = best_code;
+                const char* w16 = getenv("CTSI_CONV_M512W16");    // "0" | "1" (tuning / test aid: 4x4x32 / 4x8x16)
                 if (w16 && !strcmp(w16, "1")) p->m512_w16 = 2;
                 if (w16 && !strcmp(w16, "0")) p->m512_w16 = 0;
+                const char* t384 = getenv("CTSI_CONV_K32_384");   // "1": a 384-voxel tile of that width (test aid)
+                if (t384 && !strcmp(t384, "1")) p->m512_w16 = (p->m512_w16 == 2 || p->m512_w16 == 5) ? 5 : 3;
+                if (t384 && !strcmp(t384, "0")) p->m512_w16 = (p->m512_w16 == 2 || p->m512_w16 == 5) ? 2 : 0;
+                p->BM = (p->m512_w16 == 3 || p->m512_w16 == 5) ? 384 : 512;
             }
         }
         // few output channels (network heads: 128 -> 8, 128 -> 1): halo tile 4x2x16 x 16 couts, see conv3_head.hip

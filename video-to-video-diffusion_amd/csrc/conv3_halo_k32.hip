@@ -483,6 +483,26 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             }
         }
     }
+    // Every wave wrote exactly its own 16 MA rows of the tile, so it can stream them out without waiting for the other
+    // waves (its LDS writes and reads stay in order): one barrier less, and the waves' store streams are not bunched up
+    // behind it.  p.dbg & 128: the old order (barrier, then rows dealt round-robin to all threads), for A/B timing.
+    constexpr int CPR = BN / 8;
+    bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+    const bool wave_local = !(p.dbg & 128);
+    if (wave_local) {
+        constexpr int RPW = 16 * MA;
+#pragma unroll 4
+        for (int k = 0; k < RPW * CPR / 64; ++k) {
+            const int c = k * 64 + lane;
+            const int row = wave * RPW + c / CPR, ch = c % CPR;
+            const long long off = s_rowoff[row];
+            const int co = n0 + ch * 8;
+            if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
+                const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
+                *reinterpret_cast<uint4*>(y + off + co) = v;
+            }
+        }
+    }
     __syncthreads();
     if (want_sums && tid < BN) {
         float t1 = 0.0f, t2 = 0.0f;
@@ -496,9 +516,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         p.colsum[tg * CoutPad + n0 + tid] = t1;
         p.colsum[slab + tg * CoutPad + n0 + tid] = t2;
     }
-    {
-        constexpr int CPR = BN / 8;
-        bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+    if (!wave_local) {
         for (int c = tid; c < BM * CPR; c += NTH) {
             const int row = c / CPR, ch = c - row * CPR;
             const long long off = s_rowoff[row];

@@ -121,7 +121,7 @@ HALO3_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["16h", "16h3", "32", "16k", "32k", "32k3", "16k3", "16k3s"])
+@pytest.mark.parametrize("tile", ["16h", "16h3", "32", "16k", "32k", "32k3", "16k3", "16k3s", "32ks"])
 @pytest.mark.parametrize("name,c1,c2,cout,dims", HALO3_CASES, ids=[c[0] for c in HALO3_CASES])
 def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     """The LDS halo-tile 3x3x3 kernel (conv3_halo.hip) on aligned, ragged, multi-tile and two-source inputs;
@@ -142,7 +142,8 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile == "16k" else "0")
     monkeypatch.setenv("CTSI_CONV_K32_384", "1" if tile == "32k3" else "0")
     # "16k3": the 3x8x16 = 384-voxel tile; "16k3s": with 2-way split-K (Cin % 128 == 0 cases; the others fall back)
-    monkeypatch.setenv("CTSI_CONV_K32_SPLITK", {"16k3": "plain", "16k3s": "1"}.get(tile, "0"))
+    # "32ks": the 4x4x32 tile with 2-way split-K
+    monkeypatch.setenv("CTSI_CONV_K32_SPLITK", {"16k3": "plain", "16k3s": "1", "32ks": "512"}.get(tile, "0"))
     if tile in ("16h", "16h3"):
         monkeypatch.setenv("CTSI_CONV_H32W16", {"16h": "1", "16h3": "2"}[tile])    # 4x4x16 / 3x4x16 tiles
     monkeypatch.setenv("CTSI_CONV_M512", "1" if tile in ("32k", "16k", "32k3") else "0")

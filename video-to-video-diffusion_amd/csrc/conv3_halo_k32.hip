@@ -599,7 +599,7 @@ static void hk_launch(const Conv3HaloParams* hp, hipStream_t stream) {
 
 extern "C" size_t ctsi_conv3_halo_k32_splitk_bytes(int tiles) {   // [2 ints per tile: ticket, flag | pad to 256 B][partials]
     const size_t sync = ((size_t)tiles * 8 + 255) / 256 * 256;
-    return sync + (size_t)tiles * (3 * 8 * 4) * 512 * sizeof(float);
+    return sync + (size_t)tiles * (4 * 8 * 4) * 512 * sizeof(float);   // sized for the 512-voxel tile (128 accumulators per lane)
 }
 
 extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16, 3: 3x4x32, 5: 3x8x16 */, int bn,
@@ -618,6 +618,9 @@ extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /*
         }
     } else if (tile == 3) {
         hk_launch<3, 4, 32, 128, 2, false>(hp, (hipStream_t)stream);
+    } else if (tile == 0 && hp->ksplit == 2) {   // 4x4x32 with 2-way split-K
+        CTSI_CHECK_ARG(hp->sk_ws && hp->sk_sync && hp->nchunks % 8 == 0, "ctsi_conv3_halo_k32_launch: split-K needs its workspace");
+        hk_launch<4, 4, 32, 128, 2, false, true>(hp, (hipStream_t)stream);
     } else if (hp->tr) {
         if (tile == 2)
             hk_launch<4, 8, 16, 128, 2, true>(hp, (hipStream_t)stream);

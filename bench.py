@@ -343,7 +343,8 @@ def main():
             conv_ms = sum(v[2] for v in variants.values())
             conv_fl = sum(v[1] for v in variants.values())
             dom_key, dom = max(variants.items(), key=lambda kv: kv[1][2])   # dominant kernel = most time per step
-            kernel_names = {"m9t": "conv3_halo_k32_kernel<TR> (ConvTranspose3d (3,4,4)/(1,2,2), 12 entries per chunk, four parity classes)",
+            kernel_names = {"m9s": "conv3_halo_k32_kernel<SK> (2-way split-K form: two blocks per tile, fp32 partials handed off through a workspace)",
+                            "m9t": "conv3_halo_k32_kernel<TR> (ConvTranspose3d (3,4,4)/(1,2,2), 12 entries per chunk, four parity classes)",
                             "m9": "conv3_halo_k32_kernel (3x3x3 LDS halo tile 4x4x32 x 128 couts, 16-ch chunks, tap pairs on mfma_16x16x32_bf16)",
                             "m4": "conv3_halo32_kernel (3x3x3 LDS halo tile 4x2x32, mfma_32x32x16_bf16)",
                             "m3": "conv3_halo_kernel (3x3x3 LDS halo tile 4x4x16, mfma_16x16x32_bf16)"}

@@ -471,7 +471,8 @@ class Program:
                 co.gn_sums = prog._gn_sums.data_ptr() + gn_slot * 8
             lib.conv_fwd(plan, x1p, x2p, _ptr(holder[0]), bp, C.byref(co), sptr)
 
-        kernel = "conv_mfma_%dx%d_m%d%s" % (bm.value, bn.value, mode.value, "t" if (transposed and mode.value == 9) else "")
+        kernel = "conv_mfma_%dx%d_m%d%s%s" % (bm.value, bn.value, mode.value, "t" if (transposed and mode.value == 9) else "",
+                                              "s" if co.workspace else "")      # t: ConvTranspose form, s: split-K form
         self._emit(run, name, fl, kernel)
         return out_act, stats
 

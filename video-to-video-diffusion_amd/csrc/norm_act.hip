@@ -127,16 +127,25 @@ gn_finalize_kernel(const float* __restrict__ colsum, double* __restrict__ sums, 
             a2[u] += (double)colsum[slab + idx];
         }
     }
-    __shared__ double s1[1024], s2[1024];
-    s1[tid] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
-    s2[tid] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+    // fixed-shape reduction: butterfly inside each wave (6 steps, no barrier), then the 16 wave partials in wave order
+    double r1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), r2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        r1 += __shfl_xor(r1, off);
+        r2 += __shfl_xor(r2, off);
+    }
+    __shared__ double s1[16], s2[16];
+    if ((tid & 63) == 0) {
+        s1[tid >> 6] = r1;
+        s2[tid >> 6] = r2;
+    }
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (tid < off) {
-            s1[tid] += s1[tid + off];
-            s2[tid] += s2[tid + off];
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < 16; ++w) {
+            s1[0] += s1[w];
+            s2[0] += s2[w];
         }
-        __syncthreads();
     }
     if (tid == 0) {
         double* o = sums + ((long long)nb * groups + g) * 2;

@@ -1,7 +1,8 @@
 // 3x3x3 stride-1 convolution, 512-voxel LDS halo tile x 128 couts on v_mfma_f32_16x16x32_bf16: the K = 32 of one MFMA is
 // TWO TAPS x 16 channels.
 //
-// Why a second 512-voxel kernel: conv3_halo32m_kernel (32x32x16 MFMAs) is not cycle- but CLOCK-bound on real data -- the same
+// Why this form: the round-1 512-voxel kernel (conv3_halo32m_kernel, 32x32x16 MFMAs; now experiments/conv3_halo_m512.hip) is
+// not cycle- but CLOCK-bound on real data -- the same
 // launch on all-zero operands runs 26-33 % faster (1236 -> 1579 TFLOP/s for 384->128 @48x128^2; profiles/r02_notes.md), i.e. the
 // chip lowers its clock under the MFMA load (MI355X_MICROARCH.md, DVFS give-back) and cycles saved in the issue stream come back
 // only in part.  What raises the clock for the same FLOPs: the 16x16x32 MFMA shape (give-back item 7: ~1.12-1.15 x the FLOP/s
@@ -21,8 +22,10 @@
 #include "conv3_halo_common.h"
 #include <stdlib.h>
 
-// <TD, TH, TW, BN, UPS>: tile TD x TH x TW = 512 voxels, BN couts per block, UPS units per step (one barrier per step):
+// <TD, TH, TW, BN, UPS>: tile TD x TH x TW = 512 or 384 voxels, BN couts per block, UPS units per step (one barrier per step):
 //   <4,4,32,128,2> / <4,8,16,128,2>: per wave 64 voxels x 128 couts (32 MFMAs, 12 ds_read_b128 per unit), steps of 4 entries;
+//   <3,4,32,128,2> / <3,8,16,128,2>: 384 voxels, 48 per wave (24 MFMAs, 11 reads per unit) for levels the 512-voxel grid fills
+//     badly (48 x 32 x 32 x 512 couts: 384 blocks of 512 x 128 = 1.5 rounds of the 256 CUs, 512 of 384 x 128 = 2 rounds);
 //   <4,4,32, 64,4> / <4,8,16, 64,4>: per wave 64 x 64 (16 MFMAs, 8 reads per unit), steps of 8 entries -- the same 16 KB of
 //     weights and 64 MFMAs per wave and barrier -- for levels where 128-cout blocks leave CUs idle (48 x 32 x 32 x 512 couts:
 //     96 tiles x 4 = 384 blocks = 1.5 rounds of the 256 CUs; x 8 = 768 = 3 whole rounds).  Parity-tested, then measured
@@ -81,9 +84,10 @@ __device__ __forceinline__ void hk_wait_vm(int allowed) {   // wave-uniform `all
 // The block that finishes first parks its fp32 accumulators in a workspace ([tile][register][512 threads]: coalesced, the
 // partner has the same register <-> output mapping) and leaves; the second adds them to its own and runs the epilogue.  a + b
 // = b + a in fp32, so the result does not depend on which block comes first: bit-stable without a second pass.  Hand-off per
-// MI355X_MICROARCH.md (per-XCD L2s are not coherent): the producer's stores, __threadfence, workgroup barrier, agent-scope
-// release of a flag; the consumer's agent-scope acquire by one lane, workgroup barrier, plain loads.  The consumer waits only
-// for a block that has already taken its ticket, i.e. one that is in its epilogue: no deadlock; the spin is bounded anyway.
+// MI355X_MICROARCH.md (per-XCD L2s are not coherent), in its form WITHOUT cache maintenance: every store and load of the parked
+// bytes and of the flag is an agent-scope (sc1) access; the producer drains them (vmcnt(0), workgroup barrier) before one lane
+// raises the flag, the consumer polls with one lane, then a workgroup barrier (see the epilogue).  The consumer waits only for
+// a block that has already taken its ticket, i.e. one that is in its epilogue: no deadlock; the spin is bounded anyway.
 template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false, bool SK = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, 512)))
 conv3_halo_k32_kernel(const Conv3HaloParams p) {

@@ -39,6 +39,7 @@ struct WgradParams {
     int KH, KW, sh, sw, pd, ph, pw;
     int T, tiles_r, tiles_g, S, ksteps, kps;
     int V;  // row voxels (< 2^31)
+    int dbg;  // timing-only ablations (CTSI_DEBUG_FLAGS; wrong results): 1 no LDS-DMA after the prologue, 2 no validity masks, 64 no barrier
     unsigned mW, mH, mD;
     int shW, shH, shD;
 };
@@ -411,7 +412,9 @@ conv_wgrad_s1_kernel(const WgradParams p) {
     {                                                                                                          \
         _Pragma("unroll") for (int t_ = 0; t_ < TG; ++t_) {                                                    \
             bf16x8 b_ = bfr[SET][t_];                                                                          \
-            if (vmask[t_] != ~0ull) { /* wave-uniform */                                                       \
+            /* wave-uniform: only sub-steps whose 16 voxels hold an invalid (voxel, tap) pair pay for the masking (with   \
+               W = 48 a 64-voxel step always holds a row end, one 16-voxel sub-step in three does) */                  \
+            if (((unsigned)(vmask[t_] >> (16 * (SUB))) & 0xffffu) != 0xffffu) {                                \
                 const unsigned byte_ = (unsigned)(vmask[t_] >> (16 * (SUB) + 8 * (lane >> 5))) & 0xffu;        \
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));                                    \
                 u32x4 m_;                                                                                      \
@@ -465,6 +468,7 @@ conv_wgrad_s1_kernel(const WgradParams p) {
                 for (int t = 0; t < TG; ++t) {
                     vmask[t] = __builtin_amdgcn_ballot_w64(dh && (unsigned)(w - p.pw + t) < (unsigned)p.Wg);
                     if (BK == 32) vmask[t] |= 0xffffffff00000000ull;
+                    if (p.dbg & 2) vmask[t] = ~0ull;
                 }
             }
             const unsigned sb = lds0 + stage * STAGE;
@@ -483,7 +487,7 @@ conv_wgrad_s1_kernel(const WgradParams p) {
                     } else {
                         wg_wait_vm<0>();
                     }
-                    __builtin_amdgcn_s_barrier();
+                    if (!(p.dbg & 64)) __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     if (ks + 1 < k_end) WG_LOAD(0, lds0 + nstage * STAGE, 0);   // (NSUB is even: the last sub-step computes on set 1)
                 } else {
@@ -493,8 +497,9 @@ conv_wgrad_s1_kernel(const WgradParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 // refill of this step's stage (free since the barrier above): waves 0-3 behind the last sub-step, waves 4-7 behind
                 // the next step's first one
-                if (sub == NSUB - 1 && refill && wv < 4) issue(ks + NS, stage);
-                if (sub == 0 && wv >= 4 && ks > k_begin && ks - 1 + NS < k_end) issue(ks - 1 + NS, stage == 0 ? NS - 1 : stage - 1);
+                if (sub == NSUB - 1 && refill && wv < 4 && !(p.dbg & 1)) issue(ks + NS, stage);
+                if (sub == 0 && wv >= 4 && ks > k_begin && ks - 1 + NS < k_end && !(p.dbg & 1))
+                    issue(ks - 1 + NS, stage == 0 ? NS - 1 : stage - 1);
             }
             stage = nstage;
         }
@@ -576,15 +581,18 @@ static int wg_geometry(const ctsi_wgrad_desc* d, WgradGeom* g) {
     // Tap-sharing kernel (conv_wgrad_s1_kernel: one R slab + one halo'd G slab serve the 3 kw taps, 190 instead of 64 flop per
     // byte of LDS fill, 8-wave blocks, one per CU).  Measured against the one-tap kernel (profiles/r02_notes.md): K-steps of
     // 64 voxels + software-pipelined fragments + staggered DMA issue bring it from 10-20 % behind to par on the config-3
-    // shapes (653 / 715 / 606 / 767 vs 656 / 747 / 691 / 766 TFLOP/s) and ahead on long single-tile layers (128->128 @48x128^2:
-    // 830-867 vs 766-790): it is selected for those; CTSI_WGRAD_S1 = "0" | "64" overrides (off / on wherever it applies).
+    // shapes (653 / 715 / 606 / 767 vs 656 / 747 / 691 / 766 TFLOP/s); masking only the 16-voxel sub-steps that hold an invalid
+    // (voxel, tap) pair (the masks cost 12-18 %: knock-out) puts it ahead on single-tile layers (128->128 @4x48^3: 694 vs 674,
+    // 128-channel slice of 384->128: 843 vs 768, 128->128 @48x128^2: 852-882 vs 766-790) and leaves it behind where several
+    // channel tiles share the grid (256->256: 737 vs 757, 512->512: 619 vs 699): selected for one-tile layers of >= 300 k voxels;
+    // CTSI_WGRAD_S1 = "0" | "64" overrides (off / on wherever it applies).
     // (Its 32-voxel K-step form, 10-20 % behind, is no longer instantiated.)
     const char* s1 = getenv("CTSI_WGRAD_S1");
     const bool s1_ok = d->sh == 1 && d->sw == 1 && d->dr == d->dg && d->hr == d->hg && d->wr == d->wg && (d->kw == 3 || d->kw == 1);
     if (s1_ok && s1 && atoi(s1) == 64) {
         g->tg = d->kw;
         g->bk = 64;
-    } else if (s1_ok && !s1 && d->kw == 3 && g->tiles_r * g->tiles_g == 1 && g->V >= 600000) {
+    } else if (s1_ok && !s1 && d->kw == 3 && g->tiles_r * g->tiles_g == 1 && g->V >= 300000) {
         g->tg = 3;
         g->bk = 64;
     }
@@ -633,6 +641,10 @@ extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* g
     p.KH = d->kh; p.KW = d->kw; p.sh = d->sh; p.sw = d->sw; p.pd = d->pd; p.ph = d->ph; p.pw = d->pw;
     p.T = g.T; p.tiles_r = g.tiles_r; p.tiles_g = g.tiles_g; p.S = g.S; p.ksteps = g.ksteps; p.kps = g.kps;
     p.V = (int)g.V;
+    {
+        const char* dbgf = getenv("CTSI_DEBUG_FLAGS");   // (read per launch)
+        p.dbg = dbgf ? atoi(dbgf) : 0;
+    }
     wg_magic((unsigned)d->wr, &p.mW, &p.shW);
     wg_magic((unsigned)d->hr, &p.mH, &p.shH);
     wg_magic((unsigned)d->dr, &p.mD, &p.shD);

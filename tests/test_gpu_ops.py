@@ -191,6 +191,10 @@ def test_split_k_conv_is_bit_stable_and_matches(G, monkeypatch):
         for _ in range(4):
             prog.run()
             outs.append((G.from_act(prog, y).clone(), prog._gn_sums[slot:slot + n * 16].clone()))
+        prog.capture()                      # the hand-off also runs from a replayed hipGraph (tickets reset by the kernel)
+        for _ in range(3):
+            prog.launch()
+            outs.append((G.from_act(prog, y).clone(), prog._gn_sums[slot:slot + n * 16].clone()))
     torch.cuda.synchronize()
     assert rel_l2(outs[0][0].cpu(), ref) < CONV_TOL
     for o in outs[1:]:

@@ -97,6 +97,47 @@ def cpu_baseline(threads, latent_hw, depth):
                       f"{dt:.2f} s, {flops / dt / 1e9:.0f} GFLOP/s (the DDIM update itself is negligible)"}
 
 
+def shard_parity_check(P, E, model, ctx, dev, rank, world, dist, tol=3e-2):
+    """Multi-rank parity of the depth-sharded U-Net evaluation against the unsharded engine, per transport, on a small
+    RAGGED volume (depth 3*world + 2: slabs of 4 and 3 slices, so the interior/boundary overlap split is on): every rank
+    evaluates the unsharded program itself, the sharded epsilon is gathered along depth (padded ragged all-gather) and
+    compared on every rank; the worst rank's rel-L2 is reported.  First-contact check for csrc/comm.hip on real xGMI."""
+    L = model.vae.latent_dim
+    d, h, w = 3 * world + 2, 16, 16
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn((1, L, d, h, w), generator=gen).to(dev)
+    c = torch.randn((1, L, d, h, w), generator=gen).to(dev)
+    res = {}
+    with ctx.scope():
+        ref = E.UNetProgram(ctx, model.unet, 1, d, h, w, 2)
+        ref.load_latents(x, c)
+        ref.set_schedule([500])
+        ref.run()
+        eps_ref = ref.eps_ncdhw()
+        del ref
+    for name in ("dist", "rccl"):
+        try:
+            comm = P.DistComm() if name == "dist" else P.RcclComm.from_process_group()
+            spec = P.ShardSpec(rank, world, comm, d)
+            with ctx.scope():
+                pr = E.UNetProgram(ctx, model.unet, 1, spec.depth_local, h, w, 2, shard=spec)
+                pr.load_latents(x, c)
+                pr.set_schedule([500])
+                pr.run()
+                full = comm.gather_depth(rank, pr.eps_ncdhw(), counts=spec.depth_counts)
+                split = any(m[0] == "halo.exchange.async" for m in pr.op_meta)
+                del pr
+            torch.cuda.synchronize()
+            err = ((full.double() - eps_ref.double()).norm() / eps_ref.double().norm()).reshape(1)
+            err = torch.nan_to_num(err, nan=1e9).to(dev)
+            dist.all_reduce(err, op=dist.ReduceOp.MAX)
+            res[name] = {"rel_l2_vs_unsharded_max_over_ranks": float(err.item()), "ok": bool(err.item() < tol),
+                         "depth": d, "slabs": spec.depth_counts, "overlap_split": split}
+        except Exception as exc:   # a transport that cannot even start is reported, not fatal: the other one is timed
+            res[name] = {"ok": False, "error": f"{type(exc).__name__}: {exc}"[:300]}
+    return res
+
+
 def bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist):
     """Config 4: one 8->48 @512^2 volume, depth slab of 48/world slices per GPU.  64 sync points per step (RCCL through the
     C ABI, csrc/comm.hip): GroupNorm statistics travel with the boundary slices of the tensor they normalise.  Eager
@@ -111,9 +152,19 @@ def bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist):
     t_desc = [int(t) for t in pkg.DDIMSampler(model.diffusion, model.unet)._get_timesteps(args.ddim_steps)]
     total = args.warmup + args.steps
     reps = (total + len(t_desc) - 1) // len(t_desc) + 1
-    # RCCL issued by libctsi on the engine stream (C ABI); CTSI_SHARD_CAPTURE=1 replays the step as one hipGraph
-    comm = P.RcclComm.from_process_group() if world > 1 else P.RcclComm.single()
-    capture = os.environ.get("CTSI_SHARD_CAPTURE") == "1"
+    # Transports: "rccl" = RCCL issued by libctsi on the engine stream (C ABI, capture-safe; CTSI_SHARD_CAPTURE=1 replays
+    # the step as one hipGraph), "dist" = the same sync points through torch.distributed (nccl backend = RCCL).  On a
+    # multi-GPU run BOTH are first checked against the unsharded engine on a small ragged volume (overlap split on); the
+    # timed run uses the C-ABI transport only if its check passed (CTSI_SHARD_TRANSPORT overrides), and says which.
+    parity, transport = None, "rccl"
+    if world > 1:
+        parity = shard_parity_check(P, E, model, ctx, dev, rank, world, dist)
+        want = os.environ.get("CTSI_SHARD_TRANSPORT")
+        transport = want if want in ("rccl", "dist") else ("rccl" if parity["rccl"]["ok"] else "dist")
+        comm = P.RcclComm.from_process_group() if transport == "rccl" else P.DistComm()
+    else:
+        comm = P.RcclComm.single()
+    capture = os.environ.get("CTSI_SHARD_CAPTURE") == "1" and transport == "rccl"
     spec = P.ShardSpec(rank, world, comm, d)
     with ctx.scope():
         prog = E.UNetProgram(ctx, model.unet, 1, spec.depth_local, h, w, max_rows=len(t_desc) * reps, shard=spec)
@@ -155,7 +206,7 @@ def bench_shard(args, pkg, S, E, model, ctx, dev, rank, world, dist):
             "config": {"workload": f"DDIM-{args.ddim_steps} step on ONE latent {list(shape)} depth-sharded "
                                    f"{spec.depth_local} slices/GPU, RCCL: GroupNorm statistics travel with the boundary slices (one ncclGroup per sync point)",
                        "parallelism": f"depth-shard{world}", "sync_points_per_step": ncomm, "captured": capture,
-                       "finite_outputs": finite},
+                       "transport": transport, "parity": parity, "finite_outputs": finite},
             "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.destroy_process_group()

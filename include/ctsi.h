@@ -217,6 +217,13 @@ int ctsi_ddim_step(float* z, const float* eps, const float* noise_ncdhw, void* z
 int ctsi_ddpm_step(float* z, const float* eps, const float* noise_ncdhw, void* zin_bf16,
                    int c_total, int c_off, const float* coef, const int* step_ptr, int n, int c,
                    int d, int h, int w, void* stream);
+/* DDPM posterior with PER-SAMPLE timesteps on fp32 NCDHW tensors (replaces the arithmetic of GaussianDiffusion.
+ * _predict_z_0_from_noise, p_mean_variance and p_sample: models/diffusion.py:249-268, 270-308, 310-338).  Sample b uses
+ * coef[b*8 ..] = {sqrt(1-abar_t), sqrt(abar_t), posterior_mean_coef1, posterior_mean_coef2, [t != 0] exp(0.5 logvar)}.
+ * z0_out (may be NULL) <- (z - c0 eps) / c1, clamped to [-1, 1] when clip != 0; out (may be NULL) <- c2 z0 + c3 z
+ * (+ c4 noise when noise != NULL).  per_sample = C*D*H*W.                                                               */
+int ctsi_ddpm_posterior(const float* z, const float* eps, const float* noise, float* z0_out, float* out,
+                        const float* coef, int n, long long per_sample, int clip, void* stream);
 int ctsi_step_advance(int* step_ptr, void* stream);
 /* x <- nan_to_num(x, nan=0, posinf=1, neginf=-1) on a flat fp32 buffer (model.py:262-341) */
 int ctsi_nan_to_num_f32(float* x, long long count, void* stream);
@@ -315,6 +322,12 @@ int ctsi_slice_metrics(const float* a, const float* b, int n, int c, int d, int 
 /* hipMemsetAsync on the engine stream (zeroing GroupNorm accumulators / padded channels);
  * capturable as a memset node.                                                              */
 int ctsi_memset_async(void* ptr, int value, size_t bytes, void* stream);
+
+/* Device-side errors recorded since the last call with reset != 0 (0 on a healthy run): today the only source is a split-K
+ * conv block whose bounded wait for its partner's partial sums expired (csrc/conv3_halo_k32.hip) -- its tile is written
+ * as NaN and this sticky count is raised instead of passing a wrong result on.  *detail (may be NULL) = that tile's index.
+ * SYNCHRONOUS 8-byte device-to-host read: the samplers call it once per sample(), where they read the non-finite table. */
+int ctsi_device_error_status(unsigned int* count, unsigned int* detail, int reset);
 
 /* hipGraph helpers (one captured graph per denoising step) -------------------------------- */
 typedef struct ctsi_graph ctsi_graph;

@@ -300,6 +300,36 @@ def ddpm_sample(model: Callable, buffers: SD, shape, cond, noise_fn: Optional[Ca
     return z
 
 
+def _per_sample(buffers: SD, name: str, t: torch.Tensor, ndim: int):
+    """ref models/diffusion.py:369-385 (_extract): gather per-sample values, broadcastable over the latent"""
+    return buffers[name].gather(-1, t).float().reshape(t.shape[0], *((1,) * (ndim - 1)))
+
+
+def predict_z0_from_noise(buffers: SD, z_t, t, noise_pred):
+    """ref models/diffusion.py:249-268"""
+    return ((z_t - _per_sample(buffers, "sqrt_one_minus_alphas_cumprod", t, z_t.dim()) * noise_pred)
+            / _per_sample(buffers, "sqrt_alphas_cumprod", t, z_t.dim()))
+
+
+def p_mean_variance(model: Callable, buffers: SD, z_t, t, c, clip_denoised: bool = True):
+    """ref models/diffusion.py:270-308 -> (mean, variance, log_variance), per-sample t"""
+    z0 = predict_z0_from_noise(buffers, z_t, t, model(z_t, t, c))
+    if clip_denoised:
+        z0 = torch.clamp(z0, -1.0, 1.0)
+    mean = (_per_sample(buffers, "posterior_mean_coef1", t, z_t.dim()) * z0
+            + _per_sample(buffers, "posterior_mean_coef2", t, z_t.dim()) * z_t)
+    return (mean, _per_sample(buffers, "posterior_variance", t, z_t.dim()),
+            _per_sample(buffers, "posterior_log_variance_clipped", t, z_t.dim()))
+
+
+def p_sample(model: Callable, buffers: SD, z_t, t, c, clip_denoised: bool = True, noise=None):
+    """ref models/diffusion.py:310-338"""
+    mean, _, logvar = p_mean_variance(model, buffers, z_t, t, c, clip_denoised)
+    noise = torch.randn_like(z_t) if noise is None else noise
+    nonzero = (t != 0).float().view(-1, *([1] * (z_t.dim() - 1)))
+    return mean + nonzero * torch.exp(0.5 * logvar) * noise
+
+
 def trilinear_depth(z, d_out: int):
     """ref models/model.py:284-289"""
     return F.interpolate(z, size=(d_out, z.shape[3], z.shape[4]), mode="trilinear", align_corners=False)

@@ -112,6 +112,17 @@ with torch.no_grad():
     zx3, zc3 = formula_input((1, 4, 6, 12, 8), 12), formula_input((1, 4, 6, 12, 8), 13)
     out["unet.mid.out"] = un3(zx3, torch.tensor([999]), zc3).numpy()
 
+    # 3b. the flat-config "163 M" U-Net named by the README / north_star at FULL WIDTH, low resolution:
+    #     128 x (1,2,4), heads 8, time_embed_dim 1024, latent 4 -- 163,410,692 parameters, formula-initialised
+    leg_kw = dict(latent_dim=4, model_channels=128, num_res_blocks=2, attention_levels=[1, 2], channel_mult=(1, 2, 4),
+                  num_heads=8, time_embed_dim=1024)
+    unl = ref_unet.UNet3D(**leg_kw)
+    assert sum(p_.numel() for p_ in unl.parameters()) == 163410692
+    load_formula(unl, 21)
+    zxl, zcl = formula_input((1, 4, 6, 16, 16), 31), formula_input((1, 4, 6, 16, 16), 32)
+    out["unet.legacy163.out"] = unl(zxl, torch.tensor([321]), zcl).numpy()
+    del unl
+
     # 4. tiny VAE -------------------------------------------------------------------------------------------
     vae = ref_vae.SliceInterpolationVAE(in_channels=1, latent_dim=8, base_channels=16, scaling_factor=0.5)
     load_formula(vae, 10)
@@ -197,6 +208,23 @@ with torch.no_grad():
         pass
     model.unet.forward = orig_forward
     out["traj.ddpm.first20"] = torch.stack(traj[1:]).numpy()
+
+    # 5b. single reverse steps with PER-SAMPLE timesteps (diffusion.py:249-338): p_mean_variance with and without the
+    #     clip, _predict_z_0_from_noise, p_sample (its randn_like injected as formula noise index 0)
+    shape2 = (2, 8, 4, 8, 8)
+    z_pm, c_pm = formula_input(shape2, 23), formula_input(shape2, 24)
+    for tag, tv in (("a", [500, 37]), ("b", [0, 999])):
+        t_pm = torch.tensor(tv)
+        out[f"pmv.{tag}.t"] = np.array(tv, dtype=np.int64)
+        for clip in (True, False):
+            mean, var, logvar = model.diffusion.p_mean_variance(model.unet, z_pm, t_pm, c_pm, clip_denoised=clip)
+            out[f"pmv.{tag}.clip{int(clip)}.mean"] = mean.numpy()
+            out[f"pmv.{tag}.clip{int(clip)}.var"] = var.numpy()
+            out[f"pmv.{tag}.clip{int(clip)}.logvar"] = logvar.numpy()
+            zs = with_injected(lambda: model.diffusion.p_sample(model.unet, z_pm, t_pm, c_pm, clip_denoised=clip), first=0)
+            out[f"pmv.{tag}.clip{int(clip)}.p_sample"] = zs.numpy()
+        eps_pm = formula_input(shape2, 25)
+        out[f"pmv.{tag}.z0_from_noise"] = model.diffusion._predict_z_0_from_noise(z_pm, t_pm, eps_pm).numpy()
 
     # 6. generate() end to end on the tiny config ---------------------------------------------------------------
     v_in = formula_input((1, 1, 2, 32, 32), 16).clamp(-1, 1)

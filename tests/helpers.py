@@ -34,6 +34,8 @@ TINY_UNET = dict(latent_dim=8, model_channels=32, num_res_blocks=1, attention_le
                  num_heads=4, time_embed_dim=64)
 MID_UNET = dict(latent_dim=4, model_channels=32, num_res_blocks=2, attention_levels=[1, 2], channel_mult=(1, 2, 4),
                 num_heads=8, time_embed_dim=128)
+LEGACY163_UNET = dict(latent_dim=4, model_channels=128, num_res_blocks=2, attention_levels=[1, 2], channel_mult=(1, 2, 4),
+                      num_heads=8, time_embed_dim=1024)   # the 163,410,692-parameter flat-config U-Net
 TINY_CFG = {'in_channels': 1, 'latent_dim': 8, 'vae_base_channels': 16, 'vae_scaling_factor': 1.0,
             'unet_model_channels': 32, 'unet_num_res_blocks': 1, 'unet_attention_levels': [1],
             'unet_channel_mult': [1, 2], 'unet_num_heads': 4, 'unet_time_embed_dim': 64,

@@ -151,6 +151,28 @@ def test_unet_at_config2_latent(pkg):
     _free()
 
 
+def test_legacy163_unet_at_512_latent(pkg):
+    """The legacy 163.4 M-parameter variant named by north_star (latent 4, heads 8, time_embed_dim 1024, three
+    levels) at the benchmark's latent (1,4,48,128,128) against the fp32 oracle."""
+    torch.manual_seed(0)
+    un = pkg.UNet3D(latent_dim=4, model_channels=128, num_res_blocks=2, attention_levels=[1, 2], channel_mult=(1, 2, 4),
+                    num_heads=8, time_embed_dim=1024).eval().to(DEV)
+    assert sum(p.numel() for p in un.parameters()) == 163410692
+    sd = {k: v.detach() for k, v in un.state_dict().items()}
+    cfg = dict(model_channels=128, num_res_blocks=2, attention_levels=[1, 2], channel_mult=[1, 2, 4], num_heads=8)
+    x, c = _randn((1, 4, 48, 128, 128), 21).to(DEV), _randn((1, 4, 48, 128, 128), 22).to(DEV)
+    t = torch.tensor([500], device=DEV)
+    out = un(x, t, c)
+    with torch.no_grad():
+        ref = R.unet_forward(sd, cfg, x, t, c)
+    e = rel_l2(out, ref)
+    print(f"legacy 163.4 M U-Net (1,4,48,128,128): rel-L2 vs fp32 oracle {e:.3g}")
+    assert torch.isfinite(out).all() and e < NET_TOL
+    del ref
+    un.invalidate_engine_cache()
+    _free()
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # (c) the production VAE (base 128: 128/256/512 channels) at the config-1 and config-2 sizes
 # --------------------------------------------------------------------------------------------------------------------

@@ -198,6 +198,72 @@ def test_ddpm_first_steps(golden, pkg):
     assert max(errs) < 3e-2
 
 
+def test_single_reverse_steps_per_sample_t(golden, pkg):
+    """GaussianDiffusion.p_mean_variance / p_sample / _predict_z_0_from_noise (models/diffusion.py:249-338) with PER-SAMPLE
+    timesteps and both clip settings, against the reference's own outputs.  The U-Net evaluation is the bf16 engine
+    (NET_TOL on the mean); variance / log_variance are buffer gathers (bit-exact); the elementwise arithmetic on a given
+    epsilon is fp32 (1e-6)."""
+    model, sd, cfg = tiny_model_sd(pkg)
+    model.to(DEV)
+    g = model.diffusion
+    shape = (2, 8, 4, 8, 8)
+    z, c, eps = formula_input(shape, 23).to(DEV), formula_input(shape, 24).to(DEV), formula_input(shape, 25).to(DEV)
+    for tag in ("a", "b"):
+        t = torch.tensor(golden[f"pmv.{tag}.t"], device=DEV)
+        for clip in (1, 0):
+            mean, var, logvar = g.p_mean_variance(model.unet, z, t, c, clip_denoised=bool(clip))
+            ref = golden[f"pmv.{tag}.clip{clip}.mean"]
+            assert tuple(mean.shape) == shape and mean.dtype == torch.float32
+            # t = 999 divides by sqrt(abar) = 4.9e-5: unclipped, the mean IS the z_0 prediction times 1, dominated by that
+            # sample; the comparison is relative to the whole tensor, like the reference-under-autocast yardstick
+            e = rel_l2(mean.cpu(), ref)
+            print(f"p_mean_variance {tag} clip={clip}: rel-L2 {e:.3g}")
+            assert e < NET_TOL
+            assert np.array_equal(var.cpu().numpy(), golden[f"pmv.{tag}.clip{clip}.var"])
+            assert np.array_equal(logvar.cpu().numpy(), golden[f"pmv.{tag}.clip{clip}.logvar"])
+            assert tuple(var.shape) == (2, 1, 1, 1, 1)
+            zs = g.p_sample(model.unet, z, t, c, clip_denoised=bool(clip), noise=formula_noise(0, shape).to(DEV))
+            assert rel_l2(zs.cpu(), golden[f"pmv.{tag}.clip{clip}.p_sample"]) < NET_TOL
+        z0 = g._predict_z_0_from_noise(z, t, eps)
+        assert rel_l2(z0.cpu(), golden[f"pmv.{tag}.z0_from_noise"]) < 1e-6
+    # p_sample: default noise is drawn by torch.randn_like after the network evaluation; batch-uniform clipped steps on
+    # the engine's own U-Net take the captured-graph path and agree with the general path given the same noise
+    t_u = torch.tensor([500, 500], device=DEV)
+    torch.manual_seed(5)
+    a = g.p_sample(model.unet, z, t_u, c)
+    torch.manual_seed(5)
+    nz = torch.randn_like(z)
+    b = g.p_sample(model.unet, z, t_u, c, noise=nz)
+    assert torch.isfinite(a).all() and rel_l2(a.cpu(), b.cpu()) < 1e-5
+    # any model(z, t, c) callable works, as in the reference
+    mean_c, _, _ = g.p_mean_variance(lambda zz, tt, cc: eps, z, t_u, c)
+    z0c = g._predict_z_0_from_noise(z, t_u, eps).clamp(-1, 1)
+    ex = lambda name: g._extract(getattr(g, name), t_u, z.shape)
+    assert rel_l2(mean_c.cpu(), (ex("posterior_mean_coef1") * z0c + ex("posterior_mean_coef2") * z).cpu()) < 1e-6
+    with pytest.raises(pkg.CtsiError):
+        g._predict_z_0_from_noise(z.cpu(), t_u.cpu(), eps.cpu())
+
+
+def test_legacy163_unet_full_width_vs_reference_golden(golden, pkg):
+    """The flat-config 163,410,692-parameter U-Net (heads 8, time_embed_dim 1024, latent 4, three levels of 128 x (1,2,4)):
+    full width at low resolution against the REFERENCE's own forward (golden), formula weights."""
+    from tests.helpers import LEGACY163_UNET
+    un = pkg.UNet3D(**LEGACY163_UNET)
+    assert sum(p.numel() for p in un.parameters()) == 163410692
+    load_formula(un, 21)
+    un.to(DEV)
+    x, c = formula_input((1, 4, 6, 16, 16), 31).to(DEV), formula_input((1, 4, 6, 16, 16), 32).to(DEV)
+    out = un(x, torch.tensor([321], device=DEV), c)
+    e = rel_l2(out.cpu(), golden["unet.legacy163.out"])
+    print(f"legacy 163.4 M U-Net (1,4,6,16,16): rel-L2 vs reference golden {e:.3g}")
+    assert e < NET_TOL
+    un.attention_mode = "exact"
+    e2 = rel_l2(un(x, torch.tensor([321], device=DEV), c).cpu(), golden["unet.legacy163.out"])
+    print(f"  exact-mode attention: {e2:.3g}")
+    assert e2 < NET_TOL
+    un.invalidate_engine_cache()
+
+
 def test_generate_end_to_end(golden, pkg):
     model, sd, cfg = tiny_model_sd(pkg)
     model.to(DEV)

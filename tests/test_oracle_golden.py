@@ -182,6 +182,40 @@ def test_sampler_trajectories(golden, pkg):
         assert rel_l2(traj[i], ref[i]) < 1e-4, i
 
 
+def test_single_reverse_steps_per_sample_t(golden, pkg):
+    """p_mean_variance / p_sample / _predict_z_0_from_noise with per-sample timesteps and both clip settings
+    (models/diffusion.py:249-338) against the reference's own outputs."""
+    _, sd, cfg = tiny_model_sd(pkg)
+    shape = (2, 8, 4, 8, 8)
+    z, c, eps = formula_input(shape, 23), formula_input(shape, 24), formula_input(shape, 25)
+    model = lambda zz, tt, cc: R.unet_forward(sd, cfg, zz, tt, cc, "unet.")
+    bufs = R.diffusion_buffers("cosine", 1000)
+    for tag in ("a", "b"):
+        t = torch.tensor(golden[f"pmv.{tag}.t"])
+        for clip in (1, 0):
+            mean, var, logvar = R.p_mean_variance(model, bufs, z, t, c, bool(clip))
+            assert rel_l2(mean, golden[f"pmv.{tag}.clip{clip}.mean"]) < 1e-4
+            assert np.array_equal(var.numpy(), golden[f"pmv.{tag}.clip{clip}.var"])
+            assert np.array_equal(logvar.numpy(), golden[f"pmv.{tag}.clip{clip}.logvar"])
+            zs = R.p_sample(model, bufs, z, t, c, bool(clip), noise=formula_noise(0, shape))
+            assert rel_l2(zs, golden[f"pmv.{tag}.clip{clip}.p_sample"]) < 1e-4
+        assert rel_l2(R.predict_z0_from_noise(bufs, z, t, eps), golden[f"pmv.{tag}.z0_from_noise"]) < 1e-6
+
+
+def test_legacy163_unet_full_width(golden):
+    """The flat-config 163,410,692-parameter U-Net (128 x (1,2,4), heads 8, time_embed_dim 1024, latent 4: README /
+    north_star) at full width and low resolution against the reference's own forward."""
+    from tests.helpers import LEGACY163_UNET
+    with torch.device("meta"):
+        un = _U().UNet3D(**LEGACY163_UNET)
+    assert sum(p.numel() for p in un.parameters()) == 163410692
+    sd = formula_sd(un, 21)
+    x, c = formula_input((1, 4, 6, 16, 16), 31), formula_input((1, 4, 6, 16, 16), 32)
+    with torch.no_grad():
+        out = R.unet_forward(sd, unet_cfg(LEGACY163_UNET), x, torch.tensor([321]), c)
+    assert rel_l2(out, golden["unet.legacy163.out"]) < 2e-5
+
+
 def test_generate_end_to_end(golden, pkg):
     _, sd, cfg = tiny_model_sd(pkg)
     v_in = formula_input((1, 1, 2, 32, 32), 16).clamp(-1, 1)

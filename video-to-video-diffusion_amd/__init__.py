@@ -15,14 +15,22 @@ from .generate import generate_batch, interpolate_videos  # noqa: F401
 from . import parallel  # noqa: F401,E402
 
 
-def enable_depth_sharding(model, group=None):
+def enable_depth_sharding(model, group=None, transport=None):
     """Shard every following sampling run depth-wise over the ranks of `group` (torch.distributed must be
     initialised, one process per GPU; backend "nccl" is RCCL on ROCm).  `model` is a
     VideoToVideoDiffusion (U-Net loop and VAE decode are sharded), a UNet3D or a VideoVAE."""
+    import os
     import torch.distributed as dist
-    # GPU ranks: RCCL issued by libctsi on the engine stream (C ABI, capture-safe); anything else (the gloo CPU tests of
-    # the host logic): the same sync points over torch.distributed
-    if dist.is_initialized() and dist.get_backend(group) == "nccl":
+    # Transport of the sync points.  Default: torch.distributed's own collectives (`DistComm`; backend "nccl" IS RCCL on
+    # ROCm) -- the path every multi-process test of this repo runs.  `transport="rccl"` (or CTSI_SHARD_TRANSPORT=rccl)
+    # selects the C-ABI transport (csrc/comm.hip: one ncclGroup per sync point on the engine stream, capture-safe); it has
+    # run with ONE rank on hardware and, rank by rank, against the recording stub (tests/test_rccl_stub.py), but no
+    # multi-GPU node was available to the build: `bench.py --mode shard` checks it against the unsharded engine on the
+    # first multi-GPU run (`parity` in its JSON) before timing with it.
+    transport = (transport or os.environ.get("CTSI_SHARD_TRANSPORT", "dist")).lower()
+    if transport not in ("dist", "rccl"):
+        raise CtsiError(f"unknown depth-sharding transport '{transport}' (dist | rccl)")
+    if transport == "rccl" and dist.is_initialized() and dist.get_backend(group) == "nccl":
         comm = parallel.RcclComm.from_process_group(group)
     else:
         comm = parallel.DistComm(group)

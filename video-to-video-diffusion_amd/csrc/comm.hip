@@ -44,10 +44,18 @@ bool rccl_load() {
     if (g_rccl.ok) return true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
-    for (const char* n : names) {   // a copy already in the process (PyTorch's) first
-        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-        if (h) break;
+    // CTSI_RCCL_LIB names the collective library explicitly: another RCCL build, or the recording stub of
+    // tests/test_rccl_stub.py (which checks peers, byte counts and grouping of every sync point without a GPU)
+    const char* forced = getenv("CTSI_RCCL_LIB");
+    if (forced && *forced) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            ctsi_set_error("CTSI_RCCL_LIB=%s cannot be loaded: %s", forced, dlerror());
+            return false;
+        }
     }
+    for (int i = 0; !h && i < 3; ++i)   // a copy already in the process (PyTorch's) first
+        h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
     for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     if (!h) {
         ctsi_set_error("RCCL is not available: %s", dlerror());
@@ -91,6 +99,18 @@ struct ctsi_comm {
         }                                                                                          \
     } while (0)
 
+// Inside ncclGroupStart .. ncclGroupEnd: a failed call must not leave the thread's RCCL group open (every later RCCL call
+// of the thread -- torch.distributed's too -- would be queued and never issued: a hang instead of the reported error).
+#define CTSI_NCCL_IN_GROUP(call)                                                                   \
+    do {                                                                                           \
+        const int r_ = (call);                                                                     \
+        if (r_ != ncclSuccess_) {                                                                  \
+            ctsi_set_error("%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+            g_rccl.GroupEnd();                                                                     \
+            return CTSI_ERR_HIP;                                                                   \
+        }                                                                                          \
+    } while (0)
+
 extern "C" int ctsi_comm_unique_id(void* id128) {
     CTSI_CHECK_ARG(id128, "ctsi_comm_unique_id: null argument");
     if (!rccl_load()) return CTSI_ERR_UNSUPPORTED;
@@ -101,7 +121,9 @@ extern "C" int ctsi_comm_unique_id(void* id128) {
 }
 
 extern "C" int ctsi_comm_init(ctsi_comm** out, const void* id128, int rank, int world) {
-    CTSI_CHECK_ARG(out && world >= 1 && rank >= 0 && rank < world, "ctsi_comm_init: bad rank %d / world %d", rank, world);
+    CTSI_CHECK_ARG(out, "ctsi_comm_init: null argument");
+    *out = nullptr;   // stays null on every failure path
+    CTSI_CHECK_ARG(world >= 1 && rank >= 0 && rank < world, "ctsi_comm_init: bad rank %d / world %d", rank, world);
     ctsi_comm* c = (ctsi_comm*)calloc(1, sizeof(ctsi_comm));
     if (!c) {
         ctsi_set_error("ctsi_comm_init: out of host memory");
@@ -152,15 +174,15 @@ extern "C" int ctsi_halo_exchange_reduce(ctsi_comm* c, const void* lo_own, const
     if (!c->nccl) return CTSI_OK;   // single rank without a communicator: nothing to exchange
     CTSI_NCCL(g_rccl.GroupStart());
     if (bytes && c->rank > 0) {
-        CTSI_NCCL(g_rccl.Send(lo_own, bytes, ncclUint8_, c->rank - 1, c->nccl, st));
-        CTSI_NCCL(g_rccl.Recv(lo_halo, bytes, ncclUint8_, c->rank - 1, c->nccl, st));
+        CTSI_NCCL_IN_GROUP(g_rccl.Send(lo_own, bytes, ncclUint8_, c->rank - 1, c->nccl, st));
+        CTSI_NCCL_IN_GROUP(g_rccl.Recv(lo_halo, bytes, ncclUint8_, c->rank - 1, c->nccl, st));
     }
     if (bytes && c->rank < c->world - 1) {
-        CTSI_NCCL(g_rccl.Send(hi_own, bytes, ncclUint8_, c->rank + 1, c->nccl, st));
-        CTSI_NCCL(g_rccl.Recv(hi_halo, bytes, ncclUint8_, c->rank + 1, c->nccl, st));
+        CTSI_NCCL_IN_GROUP(g_rccl.Send(hi_own, bytes, ncclUint8_, c->rank + 1, c->nccl, st));
+        CTSI_NCCL_IN_GROUP(g_rccl.Recv(hi_halo, bytes, ncclUint8_, c->rank + 1, c->nccl, st));
     }
-    if (sums && nsums > 0) CTSI_NCCL(g_rccl.AllReduce(sums, sums, (size_t)nsums, ncclFloat64_, ncclSum_, c->nccl, st));
-    if (f32 && nf32 > 0) CTSI_NCCL(g_rccl.AllReduce(f32, f32, (size_t)nf32, ncclFloat32_, ncclSum_, c->nccl, st));
+    if (sums && nsums > 0) CTSI_NCCL_IN_GROUP(g_rccl.AllReduce(sums, sums, (size_t)nsums, ncclFloat64_, ncclSum_, c->nccl, st));
+    if (f32 && nf32 > 0) CTSI_NCCL_IN_GROUP(g_rccl.AllReduce(f32, f32, (size_t)nf32, ncclFloat32_, ncclSum_, c->nccl, st));
     CTSI_NCCL(g_rccl.GroupEnd());
     return CTSI_OK;
 }

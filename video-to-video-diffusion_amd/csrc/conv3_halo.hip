@@ -386,15 +386,14 @@ extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int 
 }
 
 extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void* stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CtsiPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         hipFuncSetAttribute((const void*)conv3_halo32_kernel<4, 2, 32, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)H32Cfg<4, 2, 32, 2, 2>::LDS_BYTES);
         hipFuncSetAttribute((const void*)conv3_halo32_kernel<4, 4, 16, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)H32Cfg<4, 4, 16, 2, 2>::LDS_BYTES);
         hipFuncSetAttribute((const void*)conv3_halo32_kernel<3, 4, 16, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)H32Cfg<3, 4, 16, 3, 1>::LDS_BYTES);
-        attr_done = true;
     }
     const int grid = hp->mtiles * hp->ntiles_n;
     constexpr int lds_232 = H32Cfg<4, 2, 32, 2, 2>::LDS_BYTES, lds_416 = H32Cfg<4, 4, 16, 2, 2>::LDS_BYTES;

@@ -88,6 +88,10 @@ __device__ __forceinline__ void hk_wait_vm(int allowed) {   // wave-uniform `all
 // bytes and of the flag is an agent-scope (sc1) access; the producer drains them (vmcnt(0), workgroup barrier) before one lane
 // raises the flag, the consumer polls with one lane, then a workgroup barrier (see the epilogue).  The consumer waits only for
 // a block that has already taken its ticket, i.e. one that is in its epilogue: no deadlock; the spin is bounded anyway.
+// Sticky device-side error word ([0] = count, [1] = last tile): set when a split-K consumer's bounded wait expires (see the
+// hand-off below); read and cleared by ctsi_device_error_status().
+__device__ unsigned int g_hk_device_error[2] = {0u, 0u};
+
 template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false, bool SK = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, 512)))
 conv3_halo_k32_kernel(const Conv3HaloParams p) {
@@ -435,10 +439,22 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
                 __builtin_amdgcn_s_sleep(4);
                 ++spins;
             }
-            // ready for the next launch on this stream
-            __hip_atomic_store(p.sk_sync + 2 * tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p.sk_sync + 2 * tile + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool expired = spins >= (1 << 22);
+            *s_role = expired ? -1 : 1;
+            if (expired) {
+                // The partner holds its ticket, i.e. it is in its epilogue: this cannot happen on a healthy device.  If it
+                // does, the result must not pass as valid: the sticky device error word makes the next
+                // ctsi_device_error_status() (the samplers read it once per sample()) fail, the tile is written as NaN,
+                // and ticket / flag are left as they are (a late partner must not meet reset flags it would then corrupt).
+                atomicAdd(&g_hk_device_error[0], 1u);
+                g_hk_device_error[1] = (unsigned)tile;
+            } else {   // ready for the next launch on this stream
+                __hip_atomic_store(p.sk_sync + 2 * tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.sk_sync + 2 * tile + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
+        __syncthreads();
+        const bool sk_expired = *s_role < 0;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < MA; ++i)
@@ -446,8 +462,9 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    acc[i][j][q] += __hip_atomic_load(wsl + (size_t)((i * NJ + j) * 4 + q) * NTH, __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT);
+                    acc[i][j][q] = sk_expired ? __builtin_nanf("")
+                                              : acc[i][j][q] + __hip_atomic_load(wsl + (size_t)((i * NJ + j) * 4 + q) * NTH,
+                                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16
     const bool want_sums = p.colsum != nullptr;
@@ -592,11 +609,8 @@ template <int TD, int TH, int TW, int BN, int UPS, bool TR, bool SK = false>
 static void hk_launch(const Conv3HaloParams* hp, hipStream_t stream) {
     using Cfg = HkCfg<TD, TH, TW, BN, UPS>;
     auto k = conv3_halo_k32_kernel<TD, TH, TW, BN, UPS, TR, SK>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static CtsiPerDeviceOnce attr_once;
+    if (attr_once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(k, dim3((TR ? 4 : 1) * (SK ? 2 : 1) * hp->mtiles * hp->ntiles_n), dim3(Cfg::NTH), Cfg::LDS_BYTES, stream,
                        *hp);
 }
@@ -636,5 +650,20 @@ extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /*
         hk_launch<4, 4, 32, 128, 2, false>(hp, (hipStream_t)stream);
     }
     CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
+// Number of device-side errors recorded since the last call with reset != 0 (0 on a healthy run), and the split-K tile of the
+// last one.  SYNCHRONOUS (a 8-byte device-to-host copy): call it where the host reads results anyway.
+extern "C" int ctsi_device_error_status(unsigned int* count, unsigned int* detail, int reset) {
+    CTSI_CHECK_ARG(count, "ctsi_device_error_status: null argument");
+    unsigned int h[2] = {0u, 0u};
+    CTSI_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hk_device_error), sizeof(h)));
+    *count = h[0];
+    if (detail) *detail = h[1];
+    if (reset && h[0]) {
+        const unsigned int z[2] = {0u, 0u};
+        CTSI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_hk_device_error), z, sizeof(z)));
+    }
     return CTSI_OK;
 }

@@ -1134,8 +1134,8 @@ static int launch_conv(const ConvKParams& k, int mode, int grid, hipStream_t st)
     constexpr int STAGE = BM * 128 + BN * 128;
     constexpr int NSTG = STAGE <= 32768 ? 4 : (STAGE <= 49152 ? 3 : 2);
     constexpr size_t lds_ring = (size_t)NSTG * STAGE + BM * 8 + WM * BN * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static CtsiPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, 3>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ring);
         hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, 0>,
@@ -1144,7 +1144,6 @@ static int launch_conv(const ConvKParams& k, int mode, int grid, hipStream_t st)
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)conv_gather_mfma_kernel<WM, WN, TM, TN, 2>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     const dim3 g(grid), b(WM * WN * 64);
     if (mode == 1)

@@ -653,11 +653,10 @@ extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* g
     if (g.tg) {
         auto k = g.tg == 3 ? conv_wgrad_s1_kernel<3, 64> : conv_wgrad_s1_kernel<1, 64>;
         const int lds = wg3::Cfg<64>::LDS_BYTES;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static CtsiPerDeviceOnce attr_once;
+        if (attr_once.first()) {
             hipFuncSetAttribute((const void*)conv_wgrad_s1_kernel<3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)conv_wgrad_s1_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
         }
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(wg3::NTH), lds, (hipStream_t)stream, p);
     } else

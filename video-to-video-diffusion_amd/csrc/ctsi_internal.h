@@ -23,6 +23,19 @@ void ctsi_set_error(const char* fmt, ...);
         }                                    \
     } while (0)
 
+// ">64 KB of dynamic LDS" is a per-device function attribute: set it once per (call site, device) -- a process may drive
+// several GPUs, one engine context each.  (Benign race: two threads may both set the same attribute.)
+struct CtsiPerDeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 #define CTSI_HIP(call)                                                                  \
     do {                                                                                \
         hipError_t e_ = (call);                                                         \

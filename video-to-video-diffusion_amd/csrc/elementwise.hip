@@ -340,6 +340,41 @@ extern "C" int ctsi_ddpm_step(float* z, const float* eps, const float* noise, vo
     return sampler_step<true>(z, eps, noise, zin, c_total, c_off, coef, step_ptr, n, c, d, h, w, nullptr, stream);
 }
 
+// ---- DDPM posterior with PER-SAMPLE timesteps (models/diffusion.py:249-338) --------------------------------------
+// fp32 NCDHW in the API layout (what p_mean_variance / p_sample take and return).  Sample b reads coefficient row
+// coef[b*8 ..]: {sqrt(1-abar_t), sqrt(abar_t), posterior_mean_coef1, posterior_mean_coef2, [t != 0] * exp(0.5 logvar)}.
+//   z0   = (z - c0 * eps) / c1           (_predict_z_0_from_noise; clamped to [-1, 1] when clip != 0)
+//   mean = c2 * z0 + c3 * z              (p_mean_variance)
+//   out  = mean + c4 * noise             (p_sample; noise == NULL: out = mean)
+__global__ void __launch_bounds__(256)
+ddpm_posterior_kernel(const float* __restrict__ z, const float* __restrict__ eps, const float* __restrict__ noise,
+                      float* __restrict__ z0_out, float* __restrict__ out, const float* __restrict__ coef,
+                      long long per_sample, long long total, int clip) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const float* cf = coef + (e / per_sample) * 8;
+        const float zt = z[e];
+        float z0 = (zt - cf[0] * eps[e]) / cf[1];
+        if (clip) z0 = fminf(fmaxf(z0, -1.0f), 1.0f);
+        if (z0_out) z0_out[e] = z0;
+        if (out) {
+            float m = cf[2] * z0 + cf[3] * zt;
+            if (noise) m += cf[4] * noise[e];
+            out[e] = m;
+        }
+    }
+}
+extern "C" int ctsi_ddpm_posterior(const float* z, const float* eps, const float* noise, float* z0_out, float* out,
+                                   const float* coef, int n, long long per_sample, int clip, void* stream) {
+    CTSI_CHECK_ARG(z && eps && coef && (z0_out || out) && n > 0 && per_sample > 0, "ctsi_ddpm_posterior: bad arguments");
+    const long long total = per_sample * n;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ddpm_posterior_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, eps, noise,
+                       z0_out, out, coef, per_sample, total, clip);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
 __global__ void step_advance_kernel(int* step_ptr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr += 1;
 }

@@ -3,7 +3,8 @@
 The ten (timesteps,) fp32 buffers are built with the same torch ops, in the same order, as the
 reference (diffusion.py:27-79) so they are bit-identical and checkpoint-compatible.  The reverse
 process runs on the HIP engine: `p_sample_loop` drives a captured U-Net step graph and the
-ctsi_ddpm_step kernel.  `training_loss` (config 3) is outside this round's scope.
+ctsi_ddpm_step kernel; single steps with per-sample timesteps (`p_mean_variance`, `p_sample`,
+`_predict_z_0_from_noise`) use ctsi_ddpm_posterior.
 """
 from __future__ import annotations
 
@@ -93,17 +94,69 @@ class GaussianDiffusion(nn.Module):
                            t_desc=list(reversed(range(self.timesteps)))[:num_steps], progress=progress,
                            noise_fn=noise_fn)
 
+    # ---- single reverse steps with per-sample timesteps (diffusion.py:249-338) -------------------------------------
+    def _posterior_rows(self, t):
+        """One coefficient row per SAMPLE for ctsi_ddpm_posterior, read from the registered buffers exactly where
+        _predict_z_0_from_noise / p_mean_variance / p_sample read them."""
+        idx = t.reshape(-1).to(device=self.betas.device, dtype=torch.long)
+        return self.ddpm_coef_rows(idx.tolist())
+
+    def _posterior(self, z_t, t, eps, noise, clip, want_z0, want_out):
+        from .engine import Ctx, _ptr
+        if not (z_t.is_cuda and eps.is_cuda):
+            raise CtsiError("the reverse-process arithmetic runs on the HIP engine: move the tensors to a ROCm device "
+                            "(there is no CPU path)")
+        if tuple(eps.shape) != tuple(z_t.shape) or t.reshape(-1).shape[0] != z_t.shape[0]:
+            raise ValueError(f"expected noise_pred of shape {tuple(z_t.shape)} and one timestep per sample, got "
+                             f"{tuple(eps.shape)} and t of shape {tuple(t.shape)}")
+        ctx = Ctx.get(z_t.device)
+        n = int(z_t.shape[0])
+        z = z_t.detach().to(torch.float32).contiguous()
+        e = eps.detach().to(torch.float32).contiguous()
+        nz = None if noise is None else noise.detach().to(device=ctx.device, dtype=torch.float32).contiguous()
+        coef = self._posterior_rows(t).to(ctx.device, torch.float32).contiguous()
+        z0 = torch.empty_like(z) if want_z0 else None
+        out = torch.empty_like(z) if want_out else None
+        with ctx.scope():
+            ctx.lib.ddpm_posterior(_ptr(z), _ptr(e), _ptr(nz), _ptr(z0), _ptr(out), _ptr(coef), n, z.numel() // n,
+                                   int(bool(clip)), ctx.sptr)
+            for tns in (z, e, nz, coef):
+                if tns is not None:
+                    tns.record_stream(ctx.stream)
+        return z0, out
+
     @torch.no_grad()
-    def p_sample(self, model, z_t, t, c, clip_denoised=True):
-        """One DDPM step (diffusion.py:310-338) for a batch-uniform t on the HIP engine."""
-        from .sampler import run_sampler
+    def _predict_z_0_from_noise(self, z_t, t, noise_pred):
+        """z_0 = (z_t - sqrt(1 - abar_t) * noise_pred) / sqrt(abar_t), per-sample t (diffusion.py:249-268)."""
+        return self._posterior(z_t, t, noise_pred, None, False, True, False)[0]
+
+    @torch.no_grad()
+    def p_mean_variance(self, model, z_t, t, c, clip_denoised=True):
+        """(mean, variance, log_variance) of q(z_{t-1} | z_t, z_0_pred) (diffusion.py:270-308).  `model` is any
+        `model(z, t, c) -> eps` callable on the ROCm device (the engine's UNet3D evaluates per-sample timesteps); the
+        posterior mean is one ctsi_ddpm_posterior launch.  variance / log_variance are the (B,1,1,1,1) buffer gathers
+        the reference returns."""
+        noise_pred = model(z_t, t, c)
+        _, mean = self._posterior(z_t, t, noise_pred, None, clip_denoised, False, True)
+        variance = self._extract(self.posterior_variance, t, z_t.shape)
+        log_variance = self._extract(self.posterior_log_variance_clipped, t, z_t.shape)
+        return mean, variance, log_variance
+
+    @torch.no_grad()
+    def p_sample(self, model, z_t, t, c, clip_denoised=True, noise=None):
+        """One DDPM step z_t -> z_{t-1} (diffusion.py:310-338); per-sample `t` and `clip_denoised=False` as in the
+        reference.  The noise is drawn with `torch.randn_like(z_t)` after the network evaluation, where the reference
+        draws it (`noise=` injects it instead: tests).  A batch-uniform clipped step on the engine's own UNet3D takes
+        the captured-graph path of the sampling loop (same arithmetic, ctsi_ddpm_step)."""
+        from .sampler import _is_engine_unet, run_sampler
         tv = [int(v) for v in t.reshape(-1).tolist()]
-        if len(set(tv)) != 1:
-            raise CtsiError("p_sample on the HIP engine needs the same timestep for every sample")
-        if not clip_denoised:
-            raise CtsiError("p_sample: clip_denoised=False is not supported by the HIP engine")
-        return run_sampler(self, model, tuple(z_t.shape), c, z_t.device, kind="ddpm", t_desc=[tv[0]],
-                           progress=False, z_init=z_t)
+        if len(set(tv)) == 1 and clip_denoised and noise is None and _is_engine_unet(model):
+            return run_sampler(self, model, tuple(z_t.shape), c, z_t.device, kind="ddpm", t_desc=[tv[0]],
+                               progress=False, z_init=z_t)
+        noise_pred = model(z_t, t, c)
+        if noise is None:
+            noise = torch.randn_like(z_t)
+        return self._posterior(z_t, t, noise_pred, noise, clip_denoised, False, True)[1]
 
     def training_loss(self, model, z_0, c, mask=None, vae=None, v_gt=None, use_ssim=False, ssim_weight=0.0,
                       t=None, noise=None):

@@ -36,10 +36,29 @@ _CTX: Dict[int, "Ctx"] = {}
 _PACKED: Dict[int, "weakref.WeakValueDictionary"] = {}
 
 
+_KEY_CHUNK = 1 << 22
+
+
 def _content_key(wt: torch.Tensor) -> Tuple[int, int, int]:
-    xi = wt.reshape(-1).view(torch.int32).to(torch.int64)
-    idx = (torch.arange(xi.numel(), device=wt.device, dtype=torch.int64) % 65521) + 1
-    return int(xi.sum()), int((xi * idx).sum()), int(xi.numel())
+    """Two independent 63-bit position-dependent checksums of the fp32 bit patterns + the element count.  Each element is
+    mixed with its index through an odd-constant multiply and an xor-shift (wrapping int64 arithmetic), so neither sum is
+    linear in the data nor periodic in the position; computed in 4 M-element chunks (16 MB of temporaries, not 3 x numel
+    int64) and read back with ONE host sync per tensor."""
+    xi = wt.reshape(-1).view(torch.int32)
+    acc = torch.zeros(2, dtype=torch.int64, device=wt.device)
+    for off in range(0, xi.numel(), _KEY_CHUNK):
+        v = xi[off:off + _KEY_CHUNK].to(torch.int64) & 0xFFFFFFFF
+        idx = torch.arange(off, off + v.numel(), device=wt.device, dtype=torch.int64)
+        h = v + 0x632BE59BD9B4E019 + idx * -0x61C8864680B583EB      # odd (golden-ratio) constant; int64 wraps
+        h = h ^ (h >> 29)
+        h = h * -0x4B47D0C5B1A3F1B5
+        h = h ^ (h >> 32)
+        g = (v ^ (idx * 0x2545F4914F6CDD1D)) * -0x395B586CA42E166B
+        g = g ^ (g >> 31)
+        acc[0] += h.sum()
+        acc[1] += g.sum()
+    a = acc.tolist()
+    return int(a[0]), int(a[1]), int(xi.numel())
 
 
 def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -490,7 +509,7 @@ class Program:
         ev_fork, ev_join = C.c_void_p(), C.c_void_p()
         lib.event_create(C.byref(ev_fork))
         lib.event_create(C.byref(ev_join))
-        self.keep.append((ev_fork, ev_join))
+        self._events = getattr(self, "_events", []) + [ev_fork, ev_join]     # destroyed with the program
         todo = [a for a in (x1, x2) if a is not None and a.halo and a.dirty]
         sl = [self._slices(a) for a in todo]
         for a in todo:
@@ -837,6 +856,8 @@ class Program:
                 self.lib.graph_destroy(self.graph)
             for p in self.plans:
                 self.lib.conv_plan_destroy(p)
+            for ev in getattr(self, "_events", ()):
+                self.lib.event_destroy(ev)
         except Exception:
             pass
 
@@ -1198,6 +1219,18 @@ def cached_program(module: nn.Module, key, build: Callable[[], Program]) -> Prog
         prog = build()
         cache[key] = prog
     return prog
+
+
+def check_device_errors(ctx: Ctx):
+    """Raise CtsiError if a kernel recorded a device-side error since the last check (ctsi_device_error_status: a split-K
+    conv block whose wait for its partner expired writes NaN and raises a sticky count instead of passing a wrong
+    result on).  One 8-byte synchronous read: called where the host reads results anyway (once per sample())."""
+    cnt, det = C.c_uint(0), C.c_uint(0)
+    ctx.stream.synchronize()       # the read below is a blocking copy on the null stream, which does not order with ours
+    ctx.lib.device_error_status(C.byref(cnt), C.byref(det), 1)
+    if cnt.value:
+        raise CtsiError(f"{cnt.value} device-side error(s) recorded by the HIP engine (last: split-K hand-off of conv tile "
+                        f"{det.value} timed out); the affected outputs were poisoned with NaN")
 
 
 def trilinear_depth(ctx: Ctx, z: torch.Tensor, d_out: int) -> torch.Tensor:

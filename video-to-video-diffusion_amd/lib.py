@@ -102,6 +102,7 @@ SIGNATURES = {
     "ctsi_trilinear_depth_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp], True),
     "ctsi_ddim_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], True),
     "ctsi_ddpm_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp], True),
+    "ctsi_ddpm_posterior": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp], True),
     "ctsi_step_advance": (_i, [_vp, _vp], True),
     "ctsi_nan_to_num_f32": (_i, [_vp, _ll, _vp], True),
     "ctsi_count_nonfinite_f32": (_i, [_vp, _ll, _i, _vp, _vp], True),
@@ -137,6 +138,7 @@ SIGNATURES = {
     "ctsi_gn_allreduce": (_i, [_vp, _vp, _i, _vp, _ll, _vp], True),
     "ctsi_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp], True),
     "ctsi_memset_async": (_i, [_vp, _i, _sz, _vp], True),
+    "ctsi_device_error_status": (_i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), _i], True),
     "ctsi_graph_begin_capture": (_i, [_vp], True),
     "ctsi_graph_end_capture": (_i, [_vp, C.POINTER(_vp)], True),
     "ctsi_graph_launch": (_i, [_vp, _vp], True),

@@ -15,7 +15,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .engine import Ctx, UNetProgram, _ptr, nan_to_num_, trilinear_depth
+from .engine import Ctx, UNetProgram, _ptr, check_device_errors, nan_to_num_, trilinear_depth
 from .lib import CtsiError
 
 logger = logging.getLogger(__name__)
@@ -176,7 +176,10 @@ def run_sampler_sharded(diffusion, unet, shape, conditioning, ctx, z0, *, kind, 
             outs.append(comm.gather_depth(comm.rank, prog.z_ncdhw(), counts=spec.depth_counts))
         if trajectory is not None:
             trajectory.extend(torch.cat(t, dim=0) for t in trajs)
-        return torch.cat(outs, dim=0)
+        res = torch.cat(outs, dim=0)
+        torch.cuda.current_stream(ctx.device).synchronize()
+        check_device_errors(ctx)
+        return res
 
 
 def run_sampler(diffusion, model, shape, conditioning, device, *, kind: str, t_desc: Sequence[int],
@@ -249,7 +252,8 @@ def run_sampler(diffusion, model, shape, conditioning, device, *, kind: str, t_d
             if trajectory is not None:
                 trajectory.append(prog.z_ncdhw())
         out = prog.z_ncdhw()
-        _log_nonfinite(kind, prog.nonfinite, steps, prog.max_rows)
+        _log_nonfinite(kind, prog.nonfinite, steps, prog.max_rows)     # (one host read: the loop itself never synchronises)
+        check_device_errors(ctx)
         return out
 
 

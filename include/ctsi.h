@@ -161,6 +161,15 @@ int ctsi_gn_apply(const void* x_bf16, void* y_bf16, const double* sums, const fl
                   int silu_pre, const float* tbias, int tbias_stride, const int* step_ptr,
                   const void* residual_bf16, int silu_post, void* stream);
 
+/* TemporalAttention, fused middle: P[n][pos][co] = bias[co] + sum_ci W[co][ci] * (gamma rstd (S - D mean) + D beta)[n][pos][ci]
+ * -- ctsi_attn_normsum and the folded (proj_out . V-projection) 1x1x1 conv (models/unet3d.py:152-153, 181-192) in one
+ * launch.  depthsum / sums / gamma / beta as for ctsi_attn_normsum; w_bf16 = bf16 [c][c] row-major (cout, cin); bias fp32 [c];
+ * out bf16 [n][h*w][c].  ctsi_attn_pv_supported(c, groups) != 0 where the kernel applies (c in {128,256,512,1024}, 8 | c / groups);
+ * other shapes use ctsi_attn_normsum + a 1x1x1 ctsi_conv_fwd. */
+int ctsi_attn_pv_supported(int c, int groups);
+int ctsi_attn_pv(const float* depthsum, const double* sums, const float* gamma, const float* beta, const void* w_bf16,
+                 const float* bias, void* out, int n, int c, int d, int h, int w, int groups, float eps, void* stream);
+
 /* TemporalAttention (models/unet3d.py:136-194) --------------------------------------------- *
  * The reference's second einsum 'bhqk,bhvc->bhqc' contracts k and v independently, so the
  * module equals proj_out(rowsum(softmax) * sum_t V_t) + x with rowsum(softmax) == 1.
@@ -324,8 +333,8 @@ int ctsi_slice_metrics(const float* a, const float* b, int n, int c, int d, int 
 int ctsi_memset_async(void* ptr, int value, size_t bytes, void* stream);
 
 /* Device-side errors recorded since the last call with reset != 0 (0 on a healthy run): today the only source is a split-K
- * conv block whose bounded wait for its partner's partial sums expired (csrc/conv3_halo_k32.hip) -- its tile is written
- * as NaN and this sticky count is raised instead of passing a wrong result on.  *detail (may be NULL) = that tile's index.
+ * conv block whose bounded wait for its partner's partial sums expired (csrc/conv3_halo_k32.hip): that tile's output is
+ * then invalid, and this sticky count is what tells the host so.  *detail (may be NULL) = that tile's index.
  * SYNCHRONOUS 8-byte device-to-host read: the samplers call it once per sample(), where they read the non-finite table. */
 int ctsi_device_error_status(unsigned int* count, unsigned int* detail, int reset);
 

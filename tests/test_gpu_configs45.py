@@ -132,8 +132,10 @@ def test_config4_vae_decode_world8_at_512(pkg):
 # ---------------------------------------------------------------------------------------------------------------------
 def test_config5_batch4_captured_step_equals_single_volume_runs(pkg):
     """Per-GPU share of config 5: 4 volumes @512^2 through ONE captured step graph (two replays = two DDIM steps, per-sample
-    timestep rows); every sample must reproduce its own B = 1 captured run.  The B = 4 plans may pick other tiles than the
-    B = 1 plans (the grid-fill score sees 4x the blocks), so equality is to kernel rounding, not bitwise."""
+    timestep rows); every sample must reproduce its own B = 1 captured run.  The B = 4 plans pick other tiles than the B = 1
+    plans for some layers (the grid-fill score sees 4x the blocks: no 384-voxel / split-K forms), i.e. other summation orders;
+    the network amplifies such bf16 re-roundings to its noise floor, exactly as sharded vs unsharded (2.1e-2 at this size):
+    the bound is the network tolerance, 3e-2, not bitwise equality."""
     torch.manual_seed(0)
     un = pkg.UNet3D(latent_dim=8).eval().to(DEV)
     g = pkg.GaussianDiffusion()
@@ -170,7 +172,7 @@ def test_config5_batch4_captured_step_equals_single_volume_runs(pkg):
         print(f"config 5 sample {b}: eps rel-L2 {e_eps:.3g}, z after 2 steps {e_z:.3g}, bit-equal {torch.equal(z4[b:b + 1], z1)}"
               + (f"; kernel variants differ: B=4 {set(kinds4) - set(kinds1)} / B=1 {set(kinds1) - set(kinds4)}"
                  if kinds4 != kinds1 else ""))
-        assert e_eps < 1e-2 and e_z < 1e-2
+        assert e_eps < NET_TOL and e_z < NET_TOL
         _free()
     un.invalidate_engine_cache()
     _free()

@@ -158,6 +158,64 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
 
 
+DOWN_CASES = [
+    # name, cin, cout, (n, d, h_in, w_in)
+    ("aligned_128_128", 128, 128, (1, 4, 8, 64)),
+    ("multi_tile_64_192", 64, 192, (1, 8, 16, 128)),
+    ("ragged_batch2_64_64", 64, 64, (2, 5, 14, 42)),
+    ("cin16_cout72", 16, 72, (1, 3, 6, 20)),
+    ("deep_k_512_256", 512, 256, (1, 3, 16, 32)),
+]
+
+
+@pytest.mark.parametrize("tile", ["32k", "16k", "32k3", "16k3", "16k3s"])
+@pytest.mark.parametrize("name,cin,cout,dims", DOWN_CASES, ids=[c[0] for c in DOWN_CASES])
+def test_downsample_conv_on_halo_tile_kernel(G, monkeypatch, name, cin, cout, dims, tile):
+    """Strided Conv3d (3,4,4)/(1,2,2)/pad 1 (models/unet3d.py:204-207, models/vae.py DownsampleBlock) on the k32 halo-tile
+    kernel (conv3_halo_k32_kernel<DS>: four input-parity sub-grids = 4 virtual chunks of 12 taps per 16 channels) in every
+    tile form incl. 2-way split-K, against F.conv3d in fp32 on the same bf16 operands and against the gather kernel."""
+    n, d, h, w = dims
+    x = bf16_round(formula_input((n, cin, d, h, w), 1))
+    wt = bf16_round(_w((cout, cin, 3, 4, 4), 3))
+    b = formula_input((cout,), 4) * 0.1
+    ref = F.conv3d(x, wt, b, stride=(1, 2, 2), padding=(1, 1, 1))
+    groups = 8
+    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
+    monkeypatch.setenv("CTSI_CONV_M512W16", "1" if tile.startswith("16") else "0")
+    monkeypatch.setenv("CTSI_CONV_K32_384", "1" if "k3" in tile else "0")
+    monkeypatch.setenv("CTSI_CONV_K32_SPLITK", "1" if tile == "16k3s" else "0")
+    import ctypes as C
+    import importlib
+    E = importlib.import_module("video-to-video-diffusion_amd.engine")
+    lib, plan, mode, bm = G.ctx().lib, C.c_void_p(), C.c_int(), C.c_int()
+    lib.conv_plan_create(C.byref(plan), C.byref(E.ConvDesc(0, 3, 4, 4, 2, 2, 1, 1, 1, n, cin, 0, cout, d, h, w, 0)))
+    lib.conv_plan_config(plan, C.byref(bm), None, C.byref(mode))
+    ws = lib.conv_plan_workspace_bytes(plan)
+    lib.conv_plan_destroy(plan)
+    assert mode.value == 9 and bm.value == (384 if "k3" in tile else 512)
+    assert (ws > 0) == (tile == "16k3s" and cin % 32 == 0)
+    y, sums = G.run_conv(x, None, wt, b, k=(3, 4, 4), s=(2, 2), want_stats=True, groups=groups)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert rel_l2(y, ref) < CONV_TOL, name
+    rg = ref.reshape(n, groups, -1).double()
+    assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+    assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
+    monkeypatch.delenv("CTSI_CONV_FORCE_HALO3")
+    monkeypatch.setenv("CTSI_CONV_K32D", "0")
+    y2, _ = G.run_conv(x, None, wt, b, k=(3, 4, 4), s=(2, 2))
+    assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    # exactness properties: a one-hot kernel tap copies the strided input; an all-ones kernel sums its window
+    if tile == "32k" and cin <= 128:
+        w1 = torch.zeros((cout, cin, 3, 4, 4))
+        for co in range(min(cout, cin)):
+            w1[co, co, 1, 2, 1] = 1.0          # out[d, y, x] = in[d, 2y + 1, 2x]
+        monkeypatch.delenv("CTSI_CONV_K32D")
+        monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
+        y3, _ = G.run_conv(x, None, w1, None, k=(3, 4, 4), s=(2, 2))
+        m = min(cout, cin)
+        assert torch.equal(y3[:, :m], x[:, :m, :, 1::2, 0::2])
+
+
 def test_split_k_conv_is_bit_stable_and_matches(G, monkeypatch):
     """2-way split-K form of the k32 kernel (conv3_halo_k32_kernel<..., SK>): the benchmark's 16-wide level shape class
     (few voxels, 512 input channels, several n-tiles, ragged edges, batch 2) -- same result whichever half finishes first
@@ -392,6 +450,57 @@ def test_temporal_attention_block(G, golden, mode):
         # the attention term itself (out - x) must match too, not just the residual-dominated sum
         term_ref = torch.tensor(golden[key]) - x
         assert rel_l2(out - bf16_round(x), term_ref) < 3e-2, (ch, mode)
+
+
+@pytest.mark.parametrize("c,groups,n,h,w", [(128, 32, 1, 4, 4), (256, 32, 2, 7, 5), (512, 32, 2, 32, 32), (1024, 32, 1, 5, 3)])
+def test_attention_fused_normsum_product(G, c, groups, n, h, w, monkeypatch):
+    """ctsi_attn_pv (normalised depth sum x folded (proj_out . V) matrix in one launch) against the fp32 formula on the
+    same bf16-rounded operands, and the whole block with it against the two-launch path (ctsi_attn_normsum + 1x1x1 conv);
+    ragged row tiles (n*h*w not a multiple of 16), several samples per tile, every supported width."""
+    import ctypes as C
+    ctx = G.ctx()
+    dev = ctx.device
+    d = 6
+    S = (formula_input((n, h * w, c), 61) * 3.0).to(dev).contiguous()
+    sums = torch.empty((n, groups, 2), dtype=torch.float64)
+    cnt = (c // groups) * d * h * w
+    sums[..., 0] = formula_input((n, groups), 62).double() * 0.1 * cnt
+    sums[..., 1] = (formula_input((n, groups), 63).double().abs() + 0.5) * cnt + sums[..., 0] ** 2 / cnt
+    gamma, beta = formula_input((c,), 64) + 1.0, formula_input((c,), 65) * 0.2
+    W = bf16_round(formula_input((c, c), 66) * (2.0 / math.sqrt(c)))
+    bias = formula_input((c,), 67) * 0.3
+    out = torch.empty((n, h * w, c), dtype=torch.bfloat16, device=dev)
+    dargs = [t.to(dev).contiguous() for t in (sums, gamma, beta, W.to(torch.bfloat16), bias)]
+    with ctx.scope():
+        assert ctx.lib.attn_pv_supported(c, groups) == 1
+        ctx.lib.attn_pv(G._ptr(S), *[G._ptr(t) for t in dargs], G._ptr(out), n, c, d, h, w, groups, 1e-5, ctx.sptr)
+    torch.cuda.synchronize()
+    mean = sums[..., 0] / cnt
+    rstd = 1.0 / torch.sqrt((sums[..., 1] / cnt - mean ** 2).clamp(min=0) + 1e-5)
+    gidx = torch.arange(c) // (c // groups)
+    xs = gamma * rstd[:, gidx].float()[:, None, :] * (S.cpu() - d * mean[:, gidx].float()[:, None, :]) + d * beta
+    ref = bf16_round(xs) @ W.t() + bias
+    assert rel_l2(out.float().cpu(), ref) < CONV_TOL
+    assert ctx.lib.attn_pv_supported(64, 8) == 0 and ctx.lib.attn_pv_supported(256, 64) == 0
+    # the block: fused vs two-launch path
+    U = importlib.import_module("video-to-video-diffusion_amd.unet3d")
+    at = U.TemporalAttention(c, 4)
+    at.load_state_dict(formula_sd(at, 7))
+    x = formula_input((n, c, 3, h, w), 68)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("CTSI_NO_ATTN_PV", "1")
+        with ctx.scope():
+            prog = G.E.Program(ctx)
+            a = G.to_act(prog, x)
+            prog.zero_gn_op()
+            y = prog.attention(at, a, "fast")
+            prog.finalize_layout()
+            assert any(m[2] == "attn_pv_mfma" for m in prog.op_meta) == (not off)
+            prog.run()
+            outs.append(G.from_act(prog, y).cpu())
+    assert rel_l2(outs[0] - bf16_round(x), outs[1] - bf16_round(x)) < 1e-2
 
 
 def test_time_embedding_rows(G, golden):

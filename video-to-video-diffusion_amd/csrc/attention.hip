@@ -150,6 +150,118 @@ extern "C" int ctsi_attn_normsum(const float* depthsum, const double* sums, cons
     return CTSI_OK;
 }
 
+// ---- fused "normalise the depth sum + (W_p W_v) product" -----------------------------------------------------------------
+// P[r][co] = bias[co] + sum_ci W[co][ci] * xs[r][ci],   xs[r][ci] = gamma rstd (S[r][ci] - D mean) + D beta   (r = n * hw + pos)
+// i.e. attn_normsum_kernel and the 1x1x1 "attn.pv" conv in ONE launch.  The product is tiny (0.1-0.5 GFLOP on <= 4096 rows)
+// and ran at launch / pipeline-fill latency on the gather conv kernel (17-22 us, 11 launches per U-Net evaluation, plus 11
+// normsum launches).  Here nothing is staged through LDS: the MFMA operand layouts are read straight from global memory --
+// an A fragment is 8 consecutive channels of one fp32 row of S (normalised in registers), a B fragment 8 consecutive input
+// channels of one row of W (bf16 [cout][cin], 0.1-0.5 MB: L2-resident) -- and ALL loads of a wave are issued before its
+// first MFMA: one memory latency per launch.  A block = 16 rows x 64 couts; its 4 waves split K (c / 4 input channels
+// each, KS = c / 128 steps of 32) and reduce their partial tiles through 16 KB of LDS.
+template <int KS>
+__global__ void __launch_bounds__(256)
+attn_pv_kernel(const float* __restrict__ S, const double* __restrict__ sums, const float* __restrict__ gamma,
+               const float* __restrict__ beta, const bf16_t* __restrict__ W, const float* __restrict__ bias,
+               bf16_t* __restrict__ P, int c, int d, int hw, int groups, float eps, int rows) {
+    __shared__ float s_part[4][16][64 + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int row0 = blockIdx.x * 16, col0 = blockIdx.y * 64;
+    int row = row0 + r16;
+    row = row < rows ? row : rows - 1;                      // (ragged last tile: clamped loads, masked stores)
+    const int nb = row / hw;
+    const int cpg = c / groups;
+    const double cnt = (double)cpg * (double)d * (double)hw;
+    const int kbase = wave * (c >> 2) + kg * 8;             // this lane's first channel of K-step 0
+    float4 a_raw[KS][2];
+    uint4 b_raw[KS][4];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int ch = kbase + ks * 32;
+        const float* sp = S + (long long)row * c + ch;
+        a_raw[ks][0] = *reinterpret_cast<const float4*>(sp);
+        a_raw[ks][1] = *reinterpret_cast<const float4*>(sp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            b_raw[ks][j] = *reinterpret_cast<const uint4*>(W + (long long)(col0 + j * 16 + r16) * c + ch);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][q] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int ch = kbase + ks * 32;
+        const int g = ch / cpg;                              // cpg % 8 == 0: the 8 channels share a group
+        const double m = sums[((long long)nb * groups + g) * 2 + 0] / cnt;
+        double var = sums[((long long)nb * groups + g) * 2 + 1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float dm = (float)d * (float)m, df = (float)d;
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch), g1 = *reinterpret_cast<const float4*>(gamma + ch + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + ch), b1 = *reinterpret_cast<const float4*>(beta + ch + 4);
+        const float sv[8] = {a_raw[ks][0].x, a_raw[ks][0].y, a_raw[ks][0].z, a_raw[ks][0].w,
+                             a_raw[ks][1].x, a_raw[ks][1].y, a_raw[ks][1].z, a_raw[ks][1].w};
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        union { bf16x8 v; unsigned u[4]; } fa;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)   // same expression as attn_normsum_kernel, rounded to bf16 like its output
+            fa.u[k] = pack_bf16x2(gv[2 * k] * rstd * (sv[2 * k] - dm) + df * bv[2 * k],
+                                  gv[2 * k + 1] * rstd * (sv[2 * k + 1] - dm) + df * bv[2 * k + 1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            union { bf16x8 v; uint4 u; } fb;
+            fb.u = b_raw[ks][j];
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb.v, acc[j], 0, 0, 0);
+        }
+    }
+    // accumulator [j][q]: row 4 kg + q, cout 16 j + r16
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_part[wave][4 * kg + q][16 * j + r16] = acc[j][q];
+    __syncthreads();
+    const int orow = tid >> 4, oc = (tid & 15) * 4;
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        o[k] = bias[col0 + oc + k] + ((s_part[0][orow][oc + k] + s_part[1][orow][oc + k]) +
+                                      (s_part[2][orow][oc + k] + s_part[3][orow][oc + k]));
+    if (row0 + orow < rows) {
+        uint2 v;
+        v.x = pack_bf16x2(o[0], o[1]);
+        v.y = pack_bf16x2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(P + (long long)(row0 + orow) * c + col0 + oc) = v;
+    }
+}
+
+extern "C" int ctsi_attn_pv_supported(int c, int groups) {
+    return (c == 128 || c == 256 || c == 512 || c == 1024) && groups > 0 && c % groups == 0 && (c / groups) % 8 == 0;
+}
+
+extern "C" int ctsi_attn_pv(const float* depthsum, const double* sums, const float* gamma, const float* beta, const void* w_bf16,
+                            const float* bias, void* out, int n, int c, int d, int h, int w, int groups, float eps, void* stream) {
+    CTSI_CHECK_ARG(depthsum && sums && gamma && beta && w_bf16 && bias && out, "ctsi_attn_pv: null argument");
+    CTSI_CHECK_ARG(ctsi_attn_pv_supported(c, groups), "ctsi_attn_pv: unsupported c=%d / groups=%d (c in {128,256,512,1024}, "
+                   "(c / groups) %% 8 == 0)", c, groups);
+    const int rows = n * h * w;
+    const dim3 grid((rows + 15) / 16, c / 64), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define CTSI_PV(KS_)                                                                                                    \
+    hipLaunchKernelGGL(attn_pv_kernel<KS_>, grid, block, 0, st, depthsum, sums, gamma, beta, (const bf16_t*)w_bf16, bias, \
+                       (bf16_t*)out, c, d, h * w, groups, eps, rows)
+    if (c == 128) CTSI_PV(1);
+    else if (c == 256) CTSI_PV(2);
+    else if (c == 512) CTSI_PV(4);
+    else CTSI_PV(8);
+#undef CTSI_PV
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}
+
 // y[n][d][pos][ch] = x + p[n][pos][ch] * (rowsum ? rowsum[n][d][pos][head(ch)] : 1)
 __global__ void __launch_bounds__(256)
 attn_broadcast_add_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ pterm,

@@ -88,17 +88,28 @@ __device__ __forceinline__ void hk_wait_vm(int allowed) {   // wave-uniform `all
 // bytes and of the flag is an agent-scope (sc1) access; the producer drains them (vmcnt(0), workgroup barrier) before one lane
 // raises the flag, the consumer polls with one lane, then a workgroup barrier (see the epilogue).  The consumer waits only for
 // a block that has already taken its ticket, i.e. one that is in its epilogue: no deadlock; the spin is bounded anyway.
+// DS = true: strided Conv3d k = (3,4,4), s = (1,2,2), p = 1 (models/unet3d.py:204-207 Downsample, models/vae.py encoder) -- the
+// mirror of the TR form.  Split the INPUT into its four (h, w) parity sub-grids in_c[d, m, n] = in[d, 2 m + py, 2 n + px]:
+// out[d, y, x] = sum over the 4 classes of a 3 x 2 x 2-tap stride-1 convolution on that sub-grid (k_h = 1 - py + 2 b reads
+// sub-grid row y + b - py, b in {0, 1}; same along w), i.e. 48 taps = 4 "virtual chunks" of 12 entries per 16 input
+// channels, every one on the 3x3x3 conv's halo tile of the OUTPUT grid.  The sub-grid is only an address pattern: the halo DMA
+// of virtual chunk vc = 4 * chunk + class fetches voxel (2 m + py, 2 n + px) -- a wave-uniform add to the class-(0, 0)
+// offsets (H_in, W_in are even, so the validity of a halo voxel does not depend on the class).  All classes accumulate into
+// the same output tile: one block = one (output tile, n-tile), K = 48 * Cin like the gather kernel, which re-staged the slab
+// per tap (505-850 TFLOP/s on the three Downsample layers of the U-Net; 27-48 % LDS bank conflicts in its 48-tap form).
+//
 // Sticky device-side error word ([0] = count, [1] = last tile): set when a split-K consumer's bounded wait expires (see the
 // hand-off below); read and cleared by ctsi_device_error_status().
 __device__ unsigned int g_hk_device_error[2] = {0u, 0u};
 
-template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false, bool SK = false>
+template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false, bool SK = false, bool DS = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, 512)))
 conv3_halo_k32_kernel(const Conv3HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = HkCfg<TD_, TH_, TW_, BN_, UPS_>;
     constexpr int UPS = Cfg::UPS, NJ = Cfg::NJ, NJH = Cfg::NJ / 2, STEP_TAPS = Cfg::STEP_TAPS;
-    constexpr int TAPS = TR ? 12 : 27;                       // entries per 16-channel chunk
+    constexpr int TAPS = (TR || DS) ? 12 : 27;               // entries per 16-channel chunk (DS: per virtual chunk)
+    static_assert(!(TR && DS), "one form at a time");
     constexpr int MA = Cfg::MA;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, HH = Cfg::HH, HW = Cfg::HW, HV = Cfg::HV;
     constexpr int HALO_INSTR = Cfg::HALO_INSTR, HALO_BYTES = Cfg::HALO_BYTES, BM = Cfg::BM, BN = Cfg::BN;
@@ -178,8 +189,13 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         const int hd = v / (HH * HW), rem = v - hd * (HH * HW);
         const int hh = rem / HW, hw = rem - hh * HW;
         const int gd = d0 + p.dshift - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-        const bool ok = (j < HALO_INSTR) && (v < HV) && gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
-        hrel[i] = ok ? ((gd - dlo) * p.Hi + gh) * p.Wi + gw : -1;
+        if (DS) {   // (gh, gw) index a parity sub-grid of Ho x Wo voxels: input voxel (2 gh + py, 2 gw + px), class added per chunk
+            const bool ok = (j < HALO_INSTR) && (v < HV) && gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Ho && gw >= 0 && gw < p.Wo;
+            hrel[i] = ok ? ((gd - dlo) * p.Hi + 2 * gh) * p.Wi + 2 * gw : -1;
+        } else {
+            const bool ok = (j < HALO_INSTR) && (v < HV) && gd >= 0 && gd < p.Di && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
+            hrel[i] = ok ? ((gd - dlo) * p.Hi + gh) * p.Wi + gw : -1;
+        }
     }
     const unsigned hq16 = (unsigned)((lane & 1) * 16);
     const int C1 = p.C1, C2 = p.C2, CoutPad = p.CoutPad;
@@ -189,7 +205,9 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     auto issue_halo = [&](int cc, int i) -> int {
         const int j = wave + NWAVE * i;
         if (j >= HALO_INSTR) return 0;
-        const int ch0 = (cbase + cc) * 16;
+        const int vc = cbase + cc;                           // DS: virtual chunk = 4 * channel chunk + parity class
+        const int ch0 = (DS ? (vc >> 2) : vc) * 16;
+        const int cadd = DS ? ((vc >> 1) & 1) * p.Wi + (vc & 1) : 0;   // sub-grid origin (py, px) in input voxels
         const bool second = ch0 >= C1;
         const unsigned cbytes = (unsigned)((second ? C2 : C1) * 2);
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? ch0 - C1 : ch0) * 2);
@@ -200,7 +218,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             asm("" : "+v"(cand));
             hsel = (i == q) ? cand : hsel;
         }
-        const unsigned voff = hsel >= 0 ? (unsigned)hsel * cbytes + hq16 : 0x80000000u;
+        const unsigned voff = hsel >= 0 ? (unsigned)(hsel + cadd) * cbytes + hq16 : 0x80000000u;
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (cc & 1) * HALO_BYTES + j * 1024));
         if (second)
             h3_dma16(rs2, dst, voff, soff);
@@ -256,6 +274,10 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             kd = 2 - (t >> 2);
             kh = ((t >> 1) & 1) ? (py ? 2 : 0) : 1;
             kw = (t & 1) ? (px ? 2 : 0) : 1;
+        } else if (DS) {                                     // class of the virtual chunk: (cbase + cc) & 3 (cbase % 4 == 0)
+            kd = t >> 2;
+            kh = ((t >> 1) & 1) + 1 - ((cc >> 1) & 1);
+            kw = (t & 1) + 1 - (cc & 1);
         } else {
             kd = t / 9;
             const int t2 = t - kd * 9;
@@ -331,7 +353,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     int n_prev = 0;                  // pieces of the most recent issue group that may stay in flight at the next barrier
     int hc = 1, hp = 0, hfree = 0;   // next halo chunk to fetch, its next piece, the first step whose group may issue it
     // halo pieces per group: a chunk lasts 6.75 steps (27 entries, UPS 2: 2 + 1 + 1 + 1), 3.4 (UPS 4) or 3 (TR: 12 entries): 3 + 2
-    constexpr int H_FIRST = (UPS == 2 && !TR) ? 2 : 3, H_LATER = (UPS == 2 && !TR) ? 1 : 3;
+    constexpr int H_FIRST = (UPS == 2 && !TR && !DS) ? 2 : 3, H_LATER = (UPS == 2 && !TR && !DS) ? 1 : 3;
     auto issue_group = [&](int s) {
         int n_halo = 0, n_w = 0;
         bool urgent = false;
@@ -439,13 +461,12 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
                 __builtin_amdgcn_s_sleep(4);
                 ++spins;
             }
-            const bool expired = spins >= (1 << 22);
-            *s_role = expired ? -1 : 1;
-            if (expired) {
+            if (spins >= (1 << 22)) {
                 // The partner holds its ticket, i.e. it is in its epilogue: this cannot happen on a healthy device.  If it
                 // does, the result must not pass as valid: the sticky device error word makes the next
-                // ctsi_device_error_status() (the samplers read it once per sample()) fail, the tile is written as NaN,
-                // and ticket / flag are left as they are (a late partner must not meet reset flags it would then corrupt).
+                // ctsi_device_error_status() (the samplers read it once per sample()) raise, and ticket / flag are left as
+                // they are (a late partner must not meet reset flags it would then corrupt).  No other work in this path:
+                // a second barrier + a select over the accumulators here cost the split-K layers 5-17 % (r03 notes).
                 atomicAdd(&g_hk_device_error[0], 1u);
                 g_hk_device_error[1] = (unsigned)tile;
             } else {   // ready for the next launch on this stream
@@ -454,17 +475,14 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             }
         }
         __syncthreads();
-        const bool sk_expired = *s_role < 0;
-        __syncthreads();
 #pragma unroll
         for (int i = 0; i < MA; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    acc[i][j][q] = sk_expired ? __builtin_nanf("")
-                                              : acc[i][j][q] + __hip_atomic_load(wsl + (size_t)((i * NJ + j) * 4 + q) * NTH,
-                                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc[i][j][q] += __hip_atomic_load(wsl + (size_t)((i * NJ + j) * 4 + q) * NTH, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
     }
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16
     const bool want_sums = p.colsum != nullptr;
@@ -555,8 +573,11 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
 //      ConvTranspose3d (cin, cout, 3,4,4) -> [class][entry q = chunk16 * 12 + t][cout_pad][16], t = (a * 2 + b) * 2 + c with
 //      kernel taps k_d = a, k_h = (py ? {2, 0} : {1, 3})[b], k_w likewise (the tap order conv3_halo_k32_kernel<TR> walks)
 __global__ void conv3_halo_k32_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int CoutPad,
-                                           int CinW, int nchunks, long long per_class, int transposed) {
-    const int taps = transposed ? 12 : 27;
+                                           int CinW, int nchunks, long long per_class, int form) {
+    // form 0: 3x3x3; 1: ConvTranspose3d (3,4,4)/(1,2,2) (4 class images); 2: Conv3d (3,4,4)/(1,2,2) (nchunks = 4 virtual chunks
+    // per 16 input channels: vc = 4 * chunk + class, entry t = (a * 2 + b) * 2 + c <-> k_d = a, k_h = 2 b + 1 - py, k_w = 2 c + 1 - px)
+    const bool transposed = form == 1;
+    const int taps = form ? 12 : 27;
     const int Q = nchunks * taps;
     const long long total = per_class * (transposed ? 4 : 1);
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -570,9 +591,13 @@ __global__ void conv3_halo_k32_pack_kernel(const float* __restrict__ w, bf16_t* 
         float v = 0.0f;
         if (q < Q) {
             const int t = (int)(q % taps), cc = (int)(q / taps);
-            const int ci = cc * 16 + e;
+            const int ci = (form == 2 ? (cc >> 2) : cc) * 16 + e;
             if (co < Cout && ci < CinW) {
-                if (transposed) {
+                if (form == 2) {
+                    const int py = (cc >> 1) & 1, px = cc & 1;
+                    const int a = t >> 2, b = (t >> 1) & 1, c = t & 1;
+                    v = w[((long long)co * CinW + ci) * 48 + (a * 4 + 2 * b + 1 - py) * 4 + 2 * c + 1 - px];
+                } else if (transposed) {
                     const int py = cls >> 1, px = cls & 1;
                     const int a = t >> 2, b = (t >> 1) & 1, c = t & 1;
                     const int ky = py ? (b ? 0 : 2) : (b ? 3 : 1), kx = px ? (c ? 0 : 2) : (c ? 3 : 1);
@@ -586,18 +611,21 @@ __global__ void conv3_halo_k32_pack_kernel(const float* __restrict__ w, bf16_t* 
     }
 }
 
-extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad, int bn, int transposed) {
-    const long long q = (long long)(cin / 16) * (transposed ? 12 : 27), step = bn == 64 ? 8 : 4;   // entries per step: 2 x UPS
-    return (size_t)(((q + step - 1) / step) * step * cout_pad * 32) * (transposed ? 4 : 1);
+// form: 0 = 3x3x3, 1 = ConvTranspose3d (3,4,4)/(1,2,2), 2 = strided Conv3d (3,4,4)/(1,2,2)
+extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad, int bn, int form) {
+    const long long q = (long long)(cin / 16) * (form == 2 ? 48 : form == 1 ? 12 : 27), step = bn == 64 ? 8 : 4;   // entries per step: 2 x UPS
+    return (size_t)(((q + step - 1) / step) * step * cout_pad * 32) * (form == 1 ? 4 : 1);
 }
 
 extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w, int bn,
-                                        int transposed, void* stream) {
-    CTSI_CHECK_ARG(w && packed && cin % 16 == 0 && (bn == 64 || bn == 128) && cout_pad % bn == 0 && (!transposed || cin_w == cin),
+                                        int form, void* stream) {
+    CTSI_CHECK_ARG(w && packed && cin % 16 == 0 && (bn == 64 || bn == 128) && cout_pad % bn == 0 && (form != 1 || cin_w == cin) &&
+                       form >= 0 && form <= 2,
                    "ctsi_conv3_halo_k32_pack: bad arguments");
-    const int nchunks = cin / 16;
-    const long long total = (long long)ctsi_conv3_halo_k32_weight_bytes(cin, cout_pad, bn, transposed) / 2;
-    const long long per_class = transposed ? total / 4 : total;
+    const int nchunks = (cin / 16) * (form == 2 ? 4 : 1);
+    const int transposed = form;
+    const long long total = (long long)ctsi_conv3_halo_k32_weight_bytes(cin, cout_pad, bn, form) / 2;
+    const long long per_class = form == 1 ? total / 4 : total;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(conv3_halo_k32_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed,
                        cout, cout_pad, cin_w, nchunks, per_class, transposed);
@@ -605,10 +633,10 @@ extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, 
     return CTSI_OK;
 }
 
-template <int TD, int TH, int TW, int BN, int UPS, bool TR, bool SK = false>
+template <int TD, int TH, int TW, int BN, int UPS, bool TR, bool SK = false, bool DS = false>
 static void hk_launch(const Conv3HaloParams* hp, hipStream_t stream) {
     using Cfg = HkCfg<TD, TH, TW, BN, UPS>;
-    auto k = conv3_halo_k32_kernel<TD, TH, TW, BN, UPS, TR, SK>;
+    auto k = conv3_halo_k32_kernel<TD, TH, TW, BN, UPS, TR, SK, DS>;
     static CtsiPerDeviceOnce attr_once;
     if (attr_once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(k, dim3((TR ? 4 : 1) * (SK ? 2 : 1) * hp->mtiles * hp->ntiles_n), dim3(Cfg::NTH), Cfg::LDS_BYTES, stream,
@@ -623,7 +651,22 @@ extern "C" size_t ctsi_conv3_halo_k32_splitk_bytes(int tiles) {   // [2 ints per
 extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16, 3: 3x4x32, 5: 3x8x16 */, int bn,
                                           void* stream) {
     CTSI_CHECK_ARG(bn == 128 && (tile == 0 || tile == 2 || tile == 3 || tile == 5), "ctsi_conv3_halo_k32_launch: bad BN %d / tile %d", bn, tile);
-    if (hp->tr && tile == 5) {
+    if (hp->ds) {   // strided Conv3d (3,4,4)/(1,2,2): nchunks counts virtual chunks (4 per 16 input channels)
+        CTSI_CHECK_ARG(!hp->tr && hp->Hi == 2 * hp->Ho && hp->Wi == 2 * hp->Wo && hp->C2 == 0 && hp->nchunks % 4 == 0,
+                       "ctsi_conv3_halo_k32_launch: the Downsample form needs even input planes and one source");
+        if (hp->ksplit == 2) {
+            CTSI_CHECK_ARG(tile == 5 && hp->sk_ws && hp->sk_sync && hp->nchunks % 8 == 0, "ctsi_conv3_halo_k32_launch: split-K needs its workspace");
+            hk_launch<3, 8, 16, 128, 2, false, true, true>(hp, (hipStream_t)stream);
+        } else if (tile == 5) {
+            hk_launch<3, 8, 16, 128, 2, false, false, true>(hp, (hipStream_t)stream);
+        } else if (tile == 3) {
+            hk_launch<3, 4, 32, 128, 2, false, false, true>(hp, (hipStream_t)stream);
+        } else if (tile == 2) {
+            hk_launch<4, 8, 16, 128, 2, false, false, true>(hp, (hipStream_t)stream);
+        } else {
+            hk_launch<4, 4, 32, 128, 2, false, false, true>(hp, (hipStream_t)stream);
+        }
+    } else if (hp->tr && tile == 5) {
         hk_launch<3, 8, 16, 128, 2, true>(hp, (hipStream_t)stream);
     } else if (hp->tr && tile == 3) {
         hk_launch<3, 4, 32, 128, 2, true>(hp, (hipStream_t)stream);

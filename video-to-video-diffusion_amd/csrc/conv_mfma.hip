@@ -648,6 +648,7 @@ struct ctsi_conv_plan {
     int fast, dshift;
     int h32_w16;    // halo3 == 2 only: 1 = 4x4x16 tile (two W-lines of 16 per A tile), 2 = 3x4x16 tile, instead of 4x2x32
     int m512_w16;   // halo3 == 7 only: tile of the k32 kernel: 0 = 4x4x32, 2 = 4x8x16, 3 = 3x4x32, 5 = 3x8x16 (384 voxels)
+    int ds;         // halo3 == 7: the strided (3,4,4)/(1,2,2) Downsample form of the k32 kernel (conv3_halo_k32.hip, DS)
     int ksplit;     // halo3 == 7, tile 5: 2 = two blocks per (tile, n-tile), each half of the input-channel chunks (needs a workspace)
     int halo3;  // 3x3x3 halo-tile kernels: 2 = conv3_halo32_kernel (conv3_halo.hip: 4x2x32 / 4x4x16 / 3x4x16 tiles), 6 = few-cout
                 // heads (conv3_head.hip), 7 = conv3_halo_k32_kernel (conv3_halo_k32.hip: 512- / 384-voxel tiles, ConvTranspose).
@@ -987,6 +988,58 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 p->BM = (p->m512_w16 == 3 || p->m512_w16 == 5) ? 384 : 512;
             }
         }
+        // Strided Conv3d (3,4,4) / (1,2,2) / pad 1 (Downsample3D, the VAE encoder's DownsampleBlock) on the k32 kernel: the four
+        // input-parity sub-grids are 3x2x2-tap stride-1 convolutions on the OUTPUT grid's halo tile (conv3_halo_k32.hip, DS =
+        // true).  CTSI_CONV_K32D=0 keeps the gather kernel (A/B timing).  Tile by the same score as the ConvTranspose form;
+        // levels whose grid stays below one round of the 256 CUs with deep K take the 2-way split-K form of the 3x8x16 tile.
+        if (!d.transposed && d.kd == 3 && d.kh == 4 && d.kw == 4 && d.sh == 2 && d.sw == 2 && d.pd == 1 && d.ph == 1 && d.pw == 1 &&
+            d.c2 == 0 && d.c1 % 16 == 0 && d.cout >= 64 && d.cout % 8 == 0 && p->CinW == p->Cin && d.hi % 2 == 0 && d.wi % 2 == 0 &&
+            extent < 2.0e9) {
+            struct { int td, th, tw, code; double eff; } cand[4] = {{4, 4, 32, 0, 1.0}, {4, 8, 16, 2, 1.0}, {3, 4, 32, 3, 0.96},
+                                                                    {3, 8, 16, 5, 0.96}};
+            double best = -1.0, best_useful = 0.0;
+            int best_code = 0;
+            long long best_blocks = 0;
+            for (auto& c : cand) {
+                const long long t = (long long)d.n * ceil_div(p->Dr, c.td) * ceil_div(p->Hr, c.th) * ceil_div(p->Wr, c.tw);
+                const long long b = t * ceil_div(d.cout, 128);
+                const double useful = (double)rows * d.n / ((double)t * c.td * c.th * c.tw);
+                const double sc = useful * (double)b / (double)(((b + 255) / 256) * 256) * c.eff;
+                if (useful < 0.7 && !getenv("CTSI_CONV_FORCE_HALO3")) continue;   // (a 32-wide tile on a 16-wide plane)
+                if (sc > best) {
+                    best = sc;
+                    best_code = c.code;
+                    best_useful = useful;
+                    best_blocks = b;
+                }
+            }
+            const char* kd_ = getenv("CTSI_CONV_K32D");       // "0": gather kernel (tuning / test aid)
+            const bool force = getenv("CTSI_CONV_FORCE_HALO3") != nullptr;
+            if ((best_useful >= 0.7 || force) && !(kd_ && !strcmp(kd_, "0")) && !getenv("CTSI_CONV_NO_HALO3")) {
+                p->halo3 = 7;
+                p->ds = 1;
+                p->BN = 128;
+                p->m512_w16 = best_code;
+                const char* w16 = getenv("CTSI_CONV_M512W16");    // "0" | "1" (tuning / test aid: 4x4x32 / 4x8x16)
+                if (w16 && !strcmp(w16, "1")) p->m512_w16 = 2;
+                if (w16 && !strcmp(w16, "0")) p->m512_w16 = 0;
+                const char* t384 = getenv("CTSI_CONV_K32_384");   // "1": a 384-voxel tile of that width (test aid)
+                if (t384 && !strcmp(t384, "1")) p->m512_w16 = (p->m512_w16 == 2 || p->m512_w16 == 5) ? 5 : 3;
+                if (t384 && !strcmp(t384, "0")) p->m512_w16 = (p->m512_w16 == 2 || p->m512_w16 == 5) ? 2 : 0;
+                // split-K: 3x8x16 tiles, two blocks per (tile, n-tile) -- when even the best tile leaves the grid at <= half a
+                // round of the CUs (48x16x16 x 512 couts: 128 blocks) and K is deep (48 taps x Cin)
+                const char* sk = getenv("CTSI_CONV_K32_SPLITK");  // "0" | "1" (tuning / test aid)
+                const long long t5 = (long long)d.n * ceil_div(p->Dr, 3) * ceil_div(p->Hr, 8) * ceil_div(p->Wr, 16) * ceil_div(d.cout, 128);
+                bool use_sk = p->Cin % 32 == 0 && p->Cin >= 256 && best_blocks <= 160 && 2 * t5 <= 512;
+                if (sk && !strcmp(sk, "0")) use_sk = false;
+                if (sk && !strcmp(sk, "1") && p->Cin % 32 == 0) use_sk = true;
+                if (use_sk) {
+                    p->m512_w16 = 5;
+                    p->ksplit = 2;
+                }
+                p->BM = (p->m512_w16 == 3 || p->m512_w16 == 5) ? 384 : 512;
+            }
+        }
         // few output channels (network heads: 128 -> 8, 128 -> 1): halo tile 4x2x16 x 16 couts, see conv3_head.hip
         const long long padded_h = (long long)ceil_div(p->Dr, 4) * ceil_div(p->Hr, 2) * ceil_div(p->Wr, 16) * 128;
         if (!p->halo3 && k3 && !p->small && d.c2 == 0 && d.c1 % 32 == 0 && d.cout <= 16 && (rows * 10 >= padded_h * 7 || getenv("CTSI_CONV_FORCE_HALO3")) &&
@@ -1058,7 +1111,7 @@ extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
     if (!p) return 0;
     if (p->halo3 == 6)   // head kernel: 8 weight rows when cout <= 8; + 1 KB: its last DMA piece is read whole
         return (size_t)p->Cin * 27 * (p->d.cout <= 8 ? 8 : 16) * 2 + 1024;
-    if (p->halo3 == 7) return ctsi_conv3_halo_k32_weight_bytes(p->Cin, p->CoutPad, p->BN, p->d.transposed);   // entries padded to whole steps
+    if (p->halo3 == 7) return ctsi_conv3_halo_k32_weight_bytes(p->Cin, p->CoutPad, p->BN, p->ds ? 2 : p->d.transposed);   // entries padded to whole steps
     if (p->halo3) return (size_t)p->Cin * 27 * p->CoutPad * 2;   // [chunk][27][cout_pad][32 | 16 ch] bf16
     return (size_t)p->nclass * p->CoutPad * p->Ktot * 2;
 }
@@ -1091,7 +1144,7 @@ extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float*
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
     if (p->halo3 == 7)
-        return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, p->BN, p->d.transposed, stream);
+        return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, p->BN, p->ds ? 2 : p->d.transposed, stream);
     if (p->halo3 == 6) {
         hipMemsetAsync((char*)packed + ctsi_conv_plan_weight_bytes(p) - 1024, 0, 1024, (hipStream_t)stream);
         return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->d.cout <= 8 ? 8 : 16, p->Cin, p->CinW, stream);
@@ -1191,7 +1244,8 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         h.dshift = p->dshift;
         h.tilesD = p->tilesD; h.tilesH = p->tilesH; h.tilesW = p->tilesW; h.tps = p->tps; h.mtiles = p->mtiles;
         h.ntiles_n = p->ntiles_n;
-        h.nchunks = p->Cin / (p->halo3 == 7 ? 16 : 32);
+        h.nchunks = p->Cin / (p->halo3 == 7 ? 16 : 32) * (p->ds ? 4 : 1);   // (Downsample form: 4 virtual chunks per 16 channels)
+        h.ds = p->ds;
         h.Cout = p->d.cout; h.CoutPad = p->CoutPad;
         h.cout_stride = o->cout_stride; h.c_off = o->c_off;
         {   // n-major block order (one n-tile's 3.5 MB weight slab at a time per XCD instead of all of them: the 48x32x32 /

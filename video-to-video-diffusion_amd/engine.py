@@ -490,8 +490,9 @@ class Program:
                 co.gn_sums = prog._gn_sums.data_ptr() + gn_slot * 8
             lib.conv_fwd(plan, x1p, x2p, _ptr(holder[0]), bp, C.byref(co), sptr)
 
-        kernel = "conv_mfma_%dx%d_m%d%s%s" % (bm.value, bn.value, mode.value, "t" if (transposed and mode.value == 9) else "",
-                                              "s" if co.workspace else "")      # t: ConvTranspose form, s: split-K form
+        form = "t" if transposed else ("d" if tuple(s) == (2, 2) else "")        # t: ConvTranspose form, d: Downsample form,
+        kernel = "conv_mfma_%dx%d_m%d%s%s" % (bm.value, bn.value, mode.value, form if mode.value == 9 else "",
+                                              "s" if co.workspace else "")      # s: split-K form
         self._emit(run, name, fl, kernel)
         return out_act, stats
 
@@ -737,15 +738,8 @@ class Program:
             self.halo_exchange(x)        # the block's input (valid already in this repo's networks: a no-op)
         gamma = self.dev_f32(lambda: m.norm.weight)
         beta = self.dev_f32(lambda: m.norm.bias)
-        xs = self.act(n, c, 1, h, w, halo=0)
         groups, eps = m.norm.num_groups, float(m.norm.eps)
-        gp, bp, xsp = _ptr(gamma), _ptr(beta), _ptr(xs.t)
-
-        def run_ns():
-            lib.attn_normsum(dsp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, xsp, n, c, d_all, h, w,
-                             groups, eps, sptr)
-
-        self._emit(run_ns, "attn.normsum")
+        gp, bp = _ptr(gamma), _ptr(beta)
 
         # fold proj_out . V-projection:  P = (Wp Wv) xs + (D Wp bv + bp)
         def wv():
@@ -759,9 +753,34 @@ class Program:
             wp = m.proj_out.weight[:, :, 0, 0, 0].double()
             return (float(d_all) * (wp @ m.qkv.bias[2 * c:3 * c].double()) + m.proj_out.bias.double()).float()
 
-        pterm, _ = self.conv("attn.pv", wpv, bpv, xs, None, k=(1, 1, 1), p=(0, 0, 0), cout=c)
-        self.pool.put(depthsum)
-        self.release(xs)
+        if lib.attn_pv_supported(c, groups) and not os.environ.get("CTSI_NO_ATTN_PV"):
+            # one launch: normalise the depth sum in registers and multiply by the folded matrix (csrc/attention.hip)
+            wbuf = self.persistent((c, c), torch.bfloat16)
+            self.pack_fns.append(lambda: wbuf.copy_(wpv().reshape(c, c).to(device=dev, dtype=torch.bfloat16)))
+            bias_pv = self.dev_f32(bpv)
+            pterm = self.act(n, c, 1, h, w, halo=0)
+            wp_, bpp, ptp = _ptr(wbuf), _ptr(bias_pv), _ptr(pterm.t)
+
+            def run_pv():
+                lib.attn_pv(dsp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, wp_, bpp, ptp, n, c, d_all, h, w,
+                            groups, eps, sptr)
+
+            fl_pv = 2.0 * n * h * w * c * c
+            self.flops += fl_pv
+            self._emit(run_pv, "attn.pv", fl_pv, "attn_pv_mfma")
+            self.pool.put(depthsum)
+        else:
+            xs = self.act(n, c, 1, h, w, halo=0)
+            xsp = _ptr(xs.t)
+
+            def run_ns():
+                lib.attn_normsum(dsp, C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), gp, bp, xsp, n, c, d_all, h, w,
+                                 groups, eps, sptr)
+
+            self._emit(run_ns, "attn.normsum")
+            pterm, _ = self.conv("attn.pv", wpv, bpv, xs, None, k=(1, 1, 1), p=(0, 0, 0), cout=c)
+            self.pool.put(depthsum)
+            self.release(xs)
         rowsum = None
         if mode == "exact":
             # evaluate the softmax row sums the reference multiplies in (they equal 1 up to rounding)
@@ -1223,14 +1242,14 @@ def cached_program(module: nn.Module, key, build: Callable[[], Program]) -> Prog
 
 def check_device_errors(ctx: Ctx):
     """Raise CtsiError if a kernel recorded a device-side error since the last check (ctsi_device_error_status: a split-K
-    conv block whose wait for its partner expired writes NaN and raises a sticky count instead of passing a wrong
-    result on).  One 8-byte synchronous read: called where the host reads results anyway (once per sample())."""
+    conv block whose wait for its partner expired raises a sticky count instead of passing a wrong result on
+    silently).  One 8-byte synchronous read: called where the host reads results anyway (once per sample())."""
     cnt, det = C.c_uint(0), C.c_uint(0)
     ctx.stream.synchronize()       # the read below is a blocking copy on the null stream, which does not order with ours
     ctx.lib.device_error_status(C.byref(cnt), C.byref(det), 1)
     if cnt.value:
         raise CtsiError(f"{cnt.value} device-side error(s) recorded by the HIP engine (last: split-K hand-off of conv tile "
-                        f"{det.value} timed out); the affected outputs were poisoned with NaN")
+                        f"{det.value} timed out); outputs computed since the last check are invalid")
 
 
 def trilinear_depth(ctx: Ctx, z: torch.Tensor, d_out: int) -> torch.Tensor:

@@ -96,6 +96,8 @@ SIGNATURES = {
     "ctsi_attn_depthsum": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_attn_depthsum_tiles": (_i, [_i, _i, _i], False),
     "ctsi_attn_normsum": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp], True),
+    "ctsi_attn_pv_supported": (_i, [_i, _i], False),
+    "ctsi_attn_pv": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp], True),
     "ctsi_attn_broadcast_add": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_attn_softmax_rowsum": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_time_embed_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp], True),

@@ -41,7 +41,8 @@ LEGACY163_CFG = {  # the flat config behind the "163 M-param U-Net" of the refer
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable with a float4 copy)
-PMC_TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")   # written by tools/pmc_traffic.py (records its commit)
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")   # written by tools/pmc_traffic.py (records its commit)
+PMC_TRAFFIC_TRAIN_FILE = os.path.join("profiles", "r03_pmc_traffic_train.json")   # the same over tools/profile_train.py
 
 
 def parse():
@@ -255,19 +256,30 @@ def bench_train(args, pkg, E, model, ctx, dev, rank, world, dist):
     finite = bool(torch.isfinite(loss).item()) and all(bool(torch.isfinite(p.grad).all().item()) for p in params[:8])
     prog = [pr for k, pr in model.unet.__dict__["_ctsi_programs"].items() if k[0] == "unet-train"][0]
     # The timed micro-steps do not step the optimizer (gradient accumulation, as in the reference's loop), so the weights
-    # never change and are never re-packed.  What an optimizer step adds to the NEXT micro-step: AdamW itself (torch) and
-    # the engine's re-pack of all 264.66 M parameters into its bf16 kernel layouts -- measured here on their own.
+    # never change and are never re-packed.  What an optimizer step adds per accumulation window, measured on its own:
+    #   fused  = optim.FusedAdamW.step(): ONE multi-tensor AdamW launch + the engine's fast re-pack of every bf16 kernel image
+    #            and fp32 operand of the training program (tables of pointers: csrc/optim.hip, engine.Program.fast_repack)
+    #   torch  = torch.optim.AdamW.step() + the generic re-pack through torch (what round 2 measured: 41 + 6 ms)
+    def timed(fn):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) * 1e3
+
+    def fresh():
+        with ctx.scope():
+            prog.ensure_fresh()
+
+    fopt = pkg.FusedAdamW(params, lr=1e-6, engine_modules=[model.unet])
+    fopt.step()                       # first call: builds the optimizer's and the program's tables
+    fused_ms = min(timed(fopt.step) for _ in range(3))
+    fused_left_ms = timed(fresh)      # nothing is left to re-pack
+    del fopt
     opt = torch.optim.AdamW(params, lr=1e-6)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
     opt.step()
-    torch.cuda.synchronize()
-    adamw_ms = (time.perf_counter() - t1) * 1e3
-    t1 = time.perf_counter()
-    with ctx.scope():
-        prog.ensure_fresh()
-    torch.cuda.synchronize()
-    repack_ms = (time.perf_counter() - t1) * 1e3
+    adamw_ms = min(timed(opt.step) for _ in range(2))
+    repack_ms = timed(fresh)
     groups = {}
     if rank == 0 and not args.no_roofline:
         with ctx.scope():
@@ -288,15 +300,20 @@ def bench_train(args, pkg, E, model, ctx, dev, rank, world, dist):
         roof = None
         if wg:
             traffic = None
-            try:  # HBM bytes per launch from rocprofv3 --pmc passes over tools/profile_train.py (tools/pmc_traffic.py)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_train.json")))["kernels"]
-                traffic = pmc["conv_wgrad_kernel"]["hbm_bytes_per_launch"]   # (round-1 PMC passes; the kernel is unchanged)
+            traffic_source = None
+            try:  # HBM bytes per launch from rocprofv3 --pmc passes over tools/profile_train.py (tools/pmc_traffic.py); null
+                pj = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_TRAIN_FILE)))   # when no file of this round exists
+                ent = max((v for k_, v in pj["kernels"].items() if k_.startswith("conv_wgrad")),
+                          key=lambda v: v["launches_FETCH_SIZE"])
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_source = {"file": PMC_TRAFFIC_TRAIN_FILE, "commit": pj.get("commit"), "method": pj.get("method")}
             except Exception:
                 pass
             ach = wg[1] / (wg[2] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv_wgrad_kernel (transposing-LDS-read MFMA weight gradient)",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                    "traffic": traffic, "launches_per_step": wg[0], "avg_launch_ms": wg[2] / wg[0],
+                    "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": wg[0],
+                    "avg_launch_ms": wg[2] / wg[0],
                     "groups": {k: {"launches": v[0], "tflops": (v[1] / (v[2] * 1e-3) / 1e12) if v[1] else None,
                                    "ms": v[2]} for k, v in groups.items()}}
         print(json.dumps({
@@ -309,9 +326,13 @@ def bench_train(args, pkg, E, model, ctx, dev, rank, world, dist):
                        "micro_batch_per_gpu": B, "parallelism": f"dp{world}", "finite": finite,
                        "samples_per_sec": args.steps * world * B / dt,
                        "unet_fwd_bwd_tflop": prog.flops / 1e12,
-                       "after_optimizer_step": {"adamw_step_ms": adamw_ms, "weight_repack_ms": repack_ms,
+                       "after_optimizer_step": {"fused_adamw_step_and_repack_ms": fused_ms,
+                                                "left_to_repack_after_fused_ms": fused_left_ms,
+                                                "torch_adamw_step_ms": adamw_ms, "generic_repack_ms": repack_ms,
                                                 "note": "not inside the timed micro-steps (no optimizer step there); "
-                                                        "paid once per optimizer step, i.e. per accumulation window"}},
+                                                        "paid once per optimizer step, i.e. per accumulation window; "
+                                                        "fused = optim.FusedAdamW (one ctsi_adamw_multi launch + fast "
+                                                        "re-pack), torch = torch.optim.AdamW + the generic re-pack"}},
             "roofline": roof, "cpu_baseline": None}))
     if dist is not None:
         dist.destroy_process_group()

@@ -332,6 +332,21 @@ int ctsi_slice_metrics(const float* a, const float* b, int n, int c, int d, int 
  * capturable as a memset node.                                                              */
 int ctsi_memset_async(void* ptr, int value, size_t bytes, void* stream);
 
+/* ---- optimizer step on the device (training/train.py:172-212 Adam / AdamW over parameter groups; trainer.py:237-247) ----
+ * ctsi_adamw_multi: ONE launch over device tables built by the host (optim.py):
+ *   tensors[i] = { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; long long numel; int group; int pad }
+ *   groups[j]  = { float lr, beta1, beta2, eps, weight_decay, step_size (= lr / (1 - beta1^t)), bc2_sqrt (= sqrt(1 - beta2^t)),
+ *                  decay (= 1 - lr weight_decay), one_m_b1, one_m_b2, grad_scale; int decoupled (1 AdamW, 0 Adam + L2),
+ *                  maximize, pad[3] }   (64 bytes; the derived constants are rounded from the host's doubles, as torch's are)
+ *   chunks[b]  = { int tensor; int first_element / 4 }: block b updates ctsi_adamw_chunk_elems() elements of that tensor.
+ * fp32 throughout, torch.optim.AdamW's single-tensor arithmetic operation by operation.
+ * ctsi_copy_scale_multi: dst[i] = scale * src[i] over a table segs[k] = { const float* src; float* dst; long long n; float
+ * scale; int pad }, pieces[b] = { int seg; int first_element / 4096 } -- every small fp32 operand of a program refreshed from
+ * the parameters in one launch. */
+int ctsi_adamw_chunk_elems(void);
+int ctsi_adamw_multi(const void* tensors, const void* groups, const void* chunks, int nchunks, void* stream);
+int ctsi_copy_scale_multi(const void* segs, const void* pieces, int npieces, void* stream);
+
 /* Device-side errors recorded since the last call with reset != 0 (0 on a healthy run): today the only source is a split-K
  * conv block whose bounded wait for its partner's partial sums expired (csrc/conv3_halo_k32.hip): that tile's output is
  * then invalid, and this sticky count is what tells the host so.  *detail (may be NULL) = that tile's index.

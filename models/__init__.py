@@ -6,5 +6,8 @@ VideoVAE = _pkg.VideoVAE
 UNet3D = _pkg.UNet3D
 GaussianDiffusion = _pkg.GaussianDiffusion
 VideoToVideoDiffusion = _pkg.VideoToVideoDiffusion
+# additive (no reference counterpart in this package): the on-device twins of torch.optim.AdamW / Adam, which the
+# reference's training/train.py:205-208 constructs
+FusedAdamW, FusedAdam = _pkg.FusedAdamW, _pkg.FusedAdam
 
-__all__ = ['VideoVAE', 'UNet3D', 'GaussianDiffusion', 'VideoToVideoDiffusion']
+__all__ = ['VideoVAE', 'UNet3D', 'GaussianDiffusion', 'VideoToVideoDiffusion', 'FusedAdamW', 'FusedAdam']

@@ -12,6 +12,7 @@ from .diffusion import GaussianDiffusion  # noqa: F401
 from .model import VideoToVideoDiffusion  # noqa: F401
 from .sampler import DDIMSampler, DDPMSampler, EDMSampler  # noqa: F401
 from .generate import generate_batch, interpolate_videos  # noqa: F401
+from .optim import FusedAdam, FusedAdamW  # noqa: F401
 from . import parallel  # noqa: F401,E402
 
 

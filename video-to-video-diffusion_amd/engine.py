@@ -191,6 +191,11 @@ class Program:
         self.weight_cache = True    # share packed weight images between programs (training programs repack in place)
         self._weights_moved = False
         self.pack_stats = dict(packed=0, shared=0)
+        # fast re-pack (see fast_repack): what every pack function reads and writes, so that the launches can be replayed from
+        # prebuilt pointer tables without touching torch
+        self._f32_meta: List[dict] = []     # dev_f32 buffers: dict(buf, make, parts, scale, fn)
+        self._pack_meta: List[dict] = []    # conv weight images: dict(plan, weight_fn, holder, fn)
+        self._fast = None
 
     def _emit(self, fn: Callable[[], None], name: str = "op", flops: float = 0.0, kernel: str = "", nbytes: float = 0.0):
         """`nbytes`: algorithmic HBM bytes of an HBM-bound op (what bench.py divides by the launch time for GB/s)."""
@@ -298,8 +303,12 @@ class Program:
     def track(self, *params: torch.Tensor):
         self._params.extend(params)
 
-    def dev_f32(self, make: Callable[[], torch.Tensor]) -> torch.Tensor:
-        """A persistent fp32 device copy of a (derived) parameter, refreshed by repack()."""
+    def dev_f32(self, make: Callable[[], torch.Tensor], parts: Optional[Sequence[Callable[[], torch.Tensor]]] = None,
+                scale: float = 1.0) -> torch.Tensor:
+        """A persistent fp32 device copy of a (derived) parameter, refreshed by repack().  `parts` (optional) says how the
+        value is made of parameter storage -- buf = scale * concat(part() for part in parts), every part a contiguous view
+        of a parameter -- so that fast_repack() can refresh it from a pointer table; a `make()` that itself returns such a
+        view needs no `parts`."""
         src = make().detach()
         buf = torch.empty(src.shape, dtype=torch.float32, device=self.ctx.device)
         self.keep.append(buf)
@@ -308,7 +317,82 @@ class Program:
             buf.copy_(make().detach().to(device=self.ctx.device, dtype=torch.float32))
 
         self.pack_fns.append(refresh)
+        self._f32_meta.append(dict(buf=buf, make=make, parts=parts, scale=float(scale), fn=refresh))
         return buf
+
+    # ---- fast re-pack after an optimizer step (optim.FusedAdamW) -------------------------------------------------------
+    # The generic repack() goes through torch for every operand (600 small copies and pack launches for the training
+    # program: ~6 ms, all of it host time).  After an optimizer step nothing but the VALUES changed, so the same device
+    # work can be issued from tables built once: ONE ctsi_copy_scale_multi launch for all small fp32 operands and one
+    # ctypes call per conv image (+ its dgrad re-layout), with every pointer precomputed.  Only programs that own their
+    # weight images (weight_cache False: the training program) take this path; operands it cannot express (values that are
+    # not contiguous views of parameter storage) keep their generic refresh function.
+    def _param_view(self, t: torch.Tensor) -> bool:
+        return (torch.is_tensor(t) and t.is_cuda and t.device == self.ctx.device and t.dtype == torch.float32
+                and t.is_contiguous() and t.numel() > 0)
+
+    def _build_fast(self):
+        import struct
+        segs, slow, packs = [], [], []
+        for ent in self._f32_meta:
+            parts = ent["parts"] if ent["parts"] is not None else [ent["make"]]
+            vals = [pt() for pt in parts]
+            if all(self._param_view(v.detach()) for v in vals) and sum(v.numel() for v in vals) == ent["buf"].numel():
+                off = 0
+                for v in vals:
+                    segs.append((v.data_ptr(), ent["buf"].data_ptr() + 4 * off, v.numel(), ent["scale"]))
+                    off += v.numel()
+            else:
+                slow.append(ent["fn"])
+        lib, sptr, dev = self.lib, self.ctx.sptr, self.ctx.device
+        for ent in self._pack_meta:
+            holder, plan, wfn = ent["holder"], ent["plan"], ent["weight_fn"]
+            fast = getattr(wfn, "fast_layout", None)
+            if holder[0] is None:
+                slow.append(ent["fn"])
+                continue
+            dst = C.c_void_p(holder[0].data_ptr())
+            if fast is not None:      # data-gradient image: flipped / transposed re-layout of a parameter view, then the pack
+                src_fn, co_w, ci_w, T, coff, cnt = fast
+                src = src_fn().detach()
+                if not self._param_view(src):
+                    slow.append(ent["fn"])
+                    continue
+                tmp = torch.empty((cnt * co_w * T,), dtype=torch.float32, device=dev)
+                self.keep.append(tmp)
+                sp, tp = C.c_void_p(src.data_ptr()), C.c_void_p(tmp.data_ptr())
+                packs.append((lib.weight_dgrad_layout, (sp, tp, co_w, ci_w, T, coff, cnt, sptr)))
+                packs.append((lib.conv_plan_pack_weights, (plan, tp, dst, sptr)))
+                continue
+            wt = wfn().detach()
+            if self._param_view(wt):
+                packs.append((lib.conv_plan_pack_weights, (plan, C.c_void_p(wt.data_ptr()), dst, sptr)))
+            else:
+                slow.append(ent["fn"])
+        seg_bytes = b"".join(struct.pack("<QQqfi", s_, d_, n_, sc, 0) for (s_, d_, n_, sc) in segs)
+        pieces = [(i, q) for i, (_, _, n_, _) in enumerate(segs) for q in range((n_ + 4095) // 4096)]
+        pc_bytes = b"".join(struct.pack("<ii", i, q) for (i, q) in pieces)
+        seg_t = torch.frombuffer(bytearray(seg_bytes or b"\0" * 32), dtype=torch.uint8).to(dev)
+        pc_t = torch.frombuffer(bytearray(pc_bytes or b"\0" * 8), dtype=torch.uint8).to(dev)
+        self._fast = dict(segs=seg_t, pieces=pc_t, npieces=len(pieces), packs=packs, slow=slow,
+                          ptrs=tuple(p.data_ptr() for p in self._params), nseg=len(segs))
+
+    def fast_repack(self):
+        """Re-pack after the parameter VALUES changed in place (same storage): see the comment above.  Falls back to the
+        generic repack() for programs that share weight images, and rebuilds its tables when a parameter moved."""
+        if self.weight_cache:
+            return self.repack()
+        if self._fast is None or self._fast["ptrs"] != tuple(p.data_ptr() for p in self._params):
+            with torch.cuda.stream(self.ctx.stream):
+                self._build_fast()
+        f = self._fast
+        with torch.cuda.stream(self.ctx.stream):
+            self.lib.copy_scale_multi(_ptr(f["segs"]), _ptr(f["pieces"]), f["npieces"], self.ctx.sptr)
+            for fn, args in f["packs"]:
+                fn(*args)
+            for fn in f["slow"]:
+                fn()
+        self._versions = self._fingerprint()
 
     def _fingerprint(self):
         """What the packed weights were made from: the tracked Parameter objects' in-place version counters and
@@ -404,7 +488,8 @@ class Program:
         lib.conv_plan_out_dims(plan, C.byref(do), C.byref(ho), C.byref(wo))
         do, ho, wo = do.value, ho.value, wo.value
         wbytes = lib.conv_plan_weight_bytes(plan)
-        bias = self.dev_f32(bias_fn) if bias_fn is not None else None
+        bias = (self.dev_f32(bias_fn, parts=getattr(bias_fn, "parts", None), scale=getattr(bias_fn, "scale", 1.0))
+                if bias_fn is not None else None)
         sptr = self.ctx.sptr
         bm, bn, mode = C.c_int(), C.c_int(), C.c_int()
         lib.conv_plan_config(plan, C.byref(bm), C.byref(bn), C.byref(mode))
@@ -436,6 +521,7 @@ class Program:
                 holder[0] = t
 
         self.pack_fns.append(pack)
+        self._pack_meta.append(dict(plan=plan, weight_fn=weight_fn, holder=holder, fn=pack))
         fl = lib.conv_plan_flops(plan)
         self.flops += fl
         self.conv_flops.append((name, fl))
@@ -529,7 +615,8 @@ class Program:
         out = self.act(x1.n, cout, d, x1.h, x1.w, halo=x1.halo)
         out.dirty = True
         se_out = out.slice_elems * 2
-        bias = self.dev_f32(bias_fn) if bias_fn is not None else None
+        bias = (self.dev_f32(bias_fn, parts=getattr(bias_fn, "parts", None), scale=getattr(bias_fn, "scale", 1.0))
+                if bias_fn is not None else None)
         parts, col_off = [], 0
         views = [("interior", d, x1.ip.value, 0 if x2 is None else x2.ip.value, out.ip.value + se_out),
                  ("lower", 3, x1.fp.value, 0 if x2 is None else x2.fp.value, out.ip.value),

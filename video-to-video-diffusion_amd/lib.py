@@ -140,6 +140,9 @@ SIGNATURES = {
     "ctsi_gn_allreduce": (_i, [_vp, _vp, _i, _vp, _ll, _vp], True),
     "ctsi_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp], True),
     "ctsi_memset_async": (_i, [_vp, _i, _sz, _vp], True),
+    "ctsi_adamw_chunk_elems": (_i, [], False),
+    "ctsi_adamw_multi": (_i, [_vp, _vp, _vp, _i, _vp], True),
+    "ctsi_copy_scale_multi": (_i, [_vp, _vp, _i, _vp], True),
     "ctsi_device_error_status": (_i, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), _i], True),
     "ctsi_graph_begin_capture": (_i, [_vp], True),
     "ctsi_graph_end_capture": (_i, [_vp, C.POINTER(_vp)], True),

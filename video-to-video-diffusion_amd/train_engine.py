@@ -83,8 +83,10 @@ class UNetTrainProgram(Program):
         self.b1 = self.dev_f32(lambda: te[1].bias)
         self.w2 = self.dev_f32(lambda: te[3].weight)
         self.b2 = self.dev_f32(lambda: te[3].bias)
-        self.w_all = self.dev_f32(lambda: torch.cat([m.time_mlp[1].weight for m in self.blocks], 0))
-        self.b_all = self.dev_f32(lambda: torch.cat([m.time_mlp[1].bias for m in self.blocks], 0))
+        self.w_all = self.dev_f32(lambda: torch.cat([m.time_mlp[1].weight for m in self.blocks], 0),
+                                  parts=[(lambda m=m: m.time_mlp[1].weight) for m in self.blocks])
+        self.b_all = self.dev_f32(lambda: torch.cat([m.time_mlp[1].bias for m in self.blocks], 0),
+                                  parts=[(lambda m=m: m.time_mlp[1].bias) for m in self.blocks])
         self.tbias = self.persistent((n, self.total_out), torch.float32, zero=True)
         self.d_tbias = self.persistent((n, self.total_out), torch.float32, zero=True)
         self.te_scratch = self.persistent((n * (self.dim + 2 * self.time_dim),), torch.float32)
@@ -294,6 +296,9 @@ class UNetTrainProgram(Program):
                     src.record_stream(self.ctx.stream)
                     return outw
 
+                # (fast_repack: the same re-layout from a pointer table, into a buffer the program keeps)
+                wfn.fast_layout = ((w_src if w_src is not None else (lambda: wparam)), co_w, ci_w, T, coff, xa.c)
+
                 self.into_grad(xa, lambda dst, wfn=wfn, cnt=xa.c: self.conv(
                     name + ".dgrad", wfn, None, g, None, k=k, s=(1, 1), p=p, cout=cnt, out=dst,
                     cin_w=(co_w if co_w != g.c else None)))
@@ -409,8 +414,11 @@ class UNetTrainProgram(Program):
 
         self._emit(run_ns, "attn.normsum")
         wv = lambda: m.qkv.weight[2 * c:3 * c]
-        u, _ = self.conv("attn.v", wv, lambda: float(d) * m.qkv.bias[2 * c:3 * c], xs, None, k=(1, 1, 1), p=(0, 0, 0),
-                         cout=c)
+        def bv():                      # the V bias is added once per depth slice of the sum
+            return float(d) * m.qkv.bias[2 * c:3 * c]
+
+        bv.parts, bv.scale = [lambda: m.qkv.bias[2 * c:3 * c]], float(d)     # (fast_repack: a scaled parameter view)
+        u, _ = self.conv("attn.v", wv, bv, xs, None, k=(1, 1, 1), p=(0, 0, 0), cout=c)
         pterm, _ = self.conv("attn.proj", lambda: m.proj_out.weight, lambda: m.proj_out.bias, u, None, k=(1, 1, 1),
                              p=(0, 0, 0), cout=c)
         out = self.act(n, c, d, h, w, halo=0)

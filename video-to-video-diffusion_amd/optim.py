@@ -56,17 +56,81 @@ class FusedAdamW(torch.optim.Optimizer):
                        for k, v in sd["state"].items()}
         return sd
 
-    def _build_tables(self, entries):
-        """entries: [(param, group index)] of the parameters that have a gradient this step."""
-        dev = entries[0][0].device
+    def _build_tables(self, entries, dev):
+        """entries: [(param, hyper-row index)] of the parameters that have a gradient this step."""
         chunk = self._lib.adamw_chunk_elems()
         chunks = []
         for i, (p, _) in enumerate(entries):
             chunks.extend((i, q * (chunk // 4)) for q in range((p.numel() + chunk - 1) // chunk))
         ck = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev)
-        self._tables = dict(key=tuple((id(p), gi) for p, gi in entries), chunks=ck, nchunks=len(chunks), dev=dev,
-                            tensors=torch.empty(len(entries) * 48, dtype=torch.uint8, device=dev),
-                            groups=torch.empty(max(len(entries), 1) * 64, dtype=torch.uint8, device=dev))
+        n = len(entries)
+        host = torch.zeros((n, 6), dtype=torch.int64)               # CtsiOptTensor rows: p, g, m, v, numel, (row | pad)
+        for i, (p, row) in enumerate(entries):
+            st = self.state[p]
+            for name in ("exp_avg", "exp_avg_sq"):
+                if st[name].device != p.device or st[name].dtype != torch.float32 or not st[name].is_contiguous():
+                    st[name] = st[name].to(device=p.device, dtype=torch.float32).contiguous()   # (a loaded state dict)
+            host[i, 0], host[i, 2], host[i, 3] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            host[i, 4], host[i, 5] = p.numel(), row                 # (little endian: the int `group` is the low word)
+        self._tables = dict(key=tuple(id(p) for p, _ in entries), rows=tuple(r for _, r in entries), chunks=ck,
+                            nchunks=len(chunks), dev=dev, host=host, gptr=None,
+                            state_ptrs=tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                                              self.state[p]["exp_avg_sq"].data_ptr()) for p, _ in entries),
+                            tensors=torch.empty((n, 6), dtype=torch.int64, device=dev),
+                            groups=torch.empty(max(n, 1) * 64, dtype=torch.uint8, device=dev))
+
+    def _hyper_rows(self):
+        """Step bookkeeping + one CtsiOptGroup row per (parameter group, step count) present.  torch counts steps per
+        parameter (a parameter without a gradient skips the step), so a group may hold several counts; the counters of
+        parameters that move together are ONE shared CPU tensor (350 tensor increments per step would cost more host time
+        than the kernel takes); a parameter that sits a step out gets its own copy first.  Returns (entries, rows)."""
+        entries, rows, row_of = [], [], {}
+        for gi, group in enumerate(self.param_groups):
+            params = group["params"]
+            live = [p for p in params if p.grad is not None]
+            if not live:
+                continue
+            state = self.state
+            first = state.get(live[0])
+            shared = first["step"] if first else None
+            uniform = (shared is not None and len(live) == len(params)
+                       and all((st := state.get(p)) is not None and len(st) and st["step"] is shared for p in live))
+            if uniform:                                  # the steady state: one counter, one row for the whole group
+                shared += 1
+                steps = [(live, float(shared))]
+            else:
+                live_counters = {id(state[q]["step"]) for q in live if state.get(q)}
+                for p in params:                         # (parameters sitting this step out leave the shared counters ...)
+                    st = state.get(p)
+                    if p.grad is None and st and id(st["step"]) in live_counters:
+                        st["step"] = st["step"].clone()
+                bumped, by_t = {}, {}
+                for p in live:                           # (... then the counters move on)
+                    if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                        raise CtsiError("FusedAdamW runs on the HIP engine: parameters must be contiguous fp32 tensors on a "
+                                        "ROCm device")
+                    st = self._init_state(p)
+                    key = id(st["step"])
+                    if key not in bumped:
+                        t_prev = float(st["step"])
+                        share = next((c for c, tp in bumped.values() if tp == t_prev), None)
+                        if share is not None:            # same count as a counter already seen: share it
+                            st["step"] = share
+                        else:
+                            st["step"] += 1
+                            bumped[key] = (st["step"], t_prev)
+                    by_t.setdefault(float(st["step"]), []).append(p)
+                steps = [(ps, t) for t, ps in by_t.items()]
+            b1, b2 = group["betas"]
+            lr, wd = float(group["lr"]), float(group["weight_decay"])
+            for ps, t in steps:
+                bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+                row_of[(gi, t)] = len(rows)
+                rows.append(struct.pack("<11f5i", lr, b1, b2, float(group["eps"]), wd, lr / bc1, math.sqrt(bc2),
+                                        1.0 - lr * wd, 1.0 - b1, 1.0 - b2, 1.0, int(self.decoupled),
+                                        int(bool(group.get("maximize", False))), 0, 0, 0))
+                entries.extend((p, row_of[(gi, t)]) for p in ps)
+        return entries, rows
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -74,73 +138,37 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        # Hyper-parameter rows: one per (parameter group, step count) actually present -- torch counts steps per parameter (a
-        # parameter without a gradient skips the step), so a group may hold several counts.  The counters of parameters that
-        # move together are ONE shared CPU tensor (350 tensor increments per step would cost more host time than the kernel
-        # takes); a parameter that sits a step out gets its own copy first.
-        entries, rows, row_of = [], [], {}
-        for gi, group in enumerate(self.param_groups):
-            bumped = {}
-            live_counters = {id(self.state[q]["step"]) for q in group["params"]
-                             if q.grad is not None and self.state.get(q)}
-            for p in group["params"]:      # (first: parameters sitting this step out leave the shared counters ...)
-                st = self.state.get(p)
-                if p.grad is None and st and id(st["step"]) in live_counters:
-                    st["step"] = st["step"].clone()
-            for p in group["params"]:      # (... then the counters move on)
-                if p.grad is None:
-                    continue
+        entries, rows = self._hyper_rows()
+        if not entries:
+            return loss
+        tb = self._tables
+        key = tuple(id(p) for p, _ in entries)
+        if (tb is None or tb["key"] != key or tb["rows"] != tuple(r for _, r in entries)
+                or tb["state_ptrs"] != tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                                              self.state[p]["exp_avg_sq"].data_ptr()) for p, _ in entries)):
+            for p, _ in entries:
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise CtsiError("FusedAdamW runs on the HIP engine: parameters must be contiguous fp32 tensors on a ROCm "
                                     "device")
-                if p.grad.is_sparse:
-                    raise CtsiError("FusedAdamW does not support sparse gradients")
-                st = self._init_state(p)
-                key = id(st["step"])
-                if key not in bumped:
-                    t_prev = float(st["step"])
-                    share = next((c for c, tp in bumped.values() if tp == t_prev), None)
-                    if share is not None:                        # same count as a counter already seen: share it
-                        st["step"] = share
-                        key = id(share)
-                    else:
-                        st["step"] += 1
-                        bumped[key] = (st["step"], t_prev)
-                t = float(st["step"])
-                rk = (gi, t)
-                if rk not in row_of:
-                    b1, b2 = group["betas"]
-                    lr = float(group["lr"])
-                    bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
-                    row_of[rk] = len(rows)
-                    wd = float(group["weight_decay"])
-                    rows.append(struct.pack("<11f5i", lr, b1, b2, float(group["eps"]), wd, lr / bc1, math.sqrt(bc2),
-                                            1.0 - lr * wd, 1.0 - b1, 1.0 - b2, 1.0, int(self.decoupled),
-                                            int(bool(group.get("maximize", False))), 0, 0, 0))
-                entries.append((p, row_of[rk]))
-        gbytes = b"".join(rows)
-        if not entries:
-            return loss
-        key = tuple((id(p), gi) for p, gi in entries)
-        if self._tables is None or self._tables["key"] != key:
-            self._build_tables(entries)
-        tb = self._tables
+            self._build_tables(entries, entries[0][0].device)
+            tb = self._tables
         dev = tb["dev"]
+        # gradients: new tensors after every backward, usually at the addresses of the previous step (caching allocator)
         grads = []
-        tbytes = bytearray()
-        for p, gi in entries:
+        for p, _ in entries:
             g = p.grad
-            if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
+            if g.dtype is not torch.float32 or g.is_sparse or g.device != p.device or not g.is_contiguous():
+                if g.is_sparse:
+                    raise CtsiError("FusedAdamW does not support sparse gradients")
                 g = g.to(device=p.device, dtype=torch.float32).contiguous()
             grads.append(g)
-            st = self.state[p]
-            for name in ("exp_avg", "exp_avg_sq"):
-                if st[name].device != p.device or st[name].dtype != torch.float32 or not st[name].is_contiguous():
-                    st[name] = st[name].to(device=p.device, dtype=torch.float32).contiguous()   # (a loaded state dict)
-            tbytes += struct.pack("<4Qq2i", p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                  p.numel(), gi, 0)
-        tb["tensors"].copy_(torch.frombuffer(tbytes, dtype=torch.uint8), non_blocking=False)
-        tb["groups"][:len(gbytes)].copy_(torch.frombuffer(bytearray(gbytes), dtype=torch.uint8), non_blocking=False)
+        gptr = tuple(g.data_ptr() for g in grads)
+        if gptr != tb["gptr"]:
+            tb["host"][:, 1] = torch.tensor(gptr, dtype=torch.int64)
+            tb["tensors"].copy_(tb["host"])
+            tb["gptr"] = gptr
+        gbytes = b"".join(rows)
+        tb["groups"][:len(gbytes)].copy_(torch.frombuffer(bytearray(gbytes), dtype=torch.uint8))
         stream = torch.cuda.current_stream(dev)
         with torch.cuda.device(dev):
             self._lib.adamw_multi(C.c_void_p(tb["tensors"].data_ptr()), C.c_void_p(tb["groups"].data_ptr()),
@@ -149,10 +177,10 @@ class FusedAdamW(torch.optim.Optimizer):
             g.record_stream(stream)
         # the update went through raw pointers: tell torch (and, through it, every engine program's fingerprint)
         bump = getattr(torch.autograd.graph, "increment_version", None)
-        for p, _ in entries:
-            if bump is not None:
-                bump(p)
-            else:  # pragma: no cover  (older torch)
+        if bump is not None:
+            bump([p for p, _ in entries])
+        else:  # pragma: no cover  (older torch)
+            for p, _ in entries:
                 p.add_(0)
         self._repack_engine_programs()
         return loss
@@ -160,8 +188,14 @@ class FusedAdamW(torch.optim.Optimizer):
     def _repack_engine_programs(self):
         """Fast re-pack of the programs (training programs: they own their weight images) of `engine_modules`."""
         for mod in self.engine_modules:
-            for m in mod.modules():
-                for prog in list(m.__dict__.get("_ctsi_programs", {}).values()):
+            subs = mod.__dict__.get("_ctsi_submodules")
+            if subs is None:
+                subs = mod.__dict__["_ctsi_submodules"] = list(mod.modules())
+            for m in subs:
+                progs = m.__dict__.get("_ctsi_programs")
+                if not progs:
+                    continue
+                for prog in list(progs.values()):
                     if not prog.weight_cache and not prog.needs_rebuild():
                         prog.ctx.enter()
                         try:

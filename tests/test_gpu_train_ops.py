@@ -137,10 +137,59 @@ def test_wgrad_tap_sharing_kernel(G, monkeypatch, name, cin, cout, dims, k):
     y.backward(dy)
     T = k ** 3
     monkeypatch.setenv("CTSI_WGRAD_S1", "64")
+    monkeypatch.setenv("CTSI_WGRAD_HALO", "0")          # (the halo-tile kernel would take the well-fitting 3x3x3 cases)
     dw = _wgrad(G, dy, x.detach(), kk, (1, 1), pp, T, tuple(wt.shape), (cin * T, T, 1))
     assert rel_l2(dw.cpu(), wt.grad) <= 3e-3, name
     dw2 = _wgrad(G, dy, x.detach(), kk, (1, 1), pp, T, tuple(wt.shape), (cin * T, T, 1))
     assert torch.equal(dw, dw2)
+
+
+HALO_WG_CASES = [
+    # name, cin, cout, (n,d,h,w), expected tile code (1: 3x8x8, 2: 6x4x8, 3: 3x4x16)
+    ("aligned_128_128", 128, 128, (1, 6, 8, 16), 1),
+    ("batch2_ragged_64_192", 64, 192, (2, 5, 16, 24), 1),           # D = 5: ragged depth tiles; two cout tiles (192 of 256)
+    ("cin16_cout72", 16, 72, (1, 3, 8, 8), 1),
+    ("tile_3x4x16", 32, 128, (1, 3, 4, 32), 3),
+    ("tile_6x4x8", 32, 64, (1, 6, 4, 16), 2),
+    ("ragged_planes_12x12", 64, 128, (1, 6, 12, 12), 2),            # 12-wide planes: W tiles of 8 cover 16 (75 %)
+    ("multi_slice_256_256", 256, 256, (1, 12, 16, 16), 1),          # several voxel-tile slices per (chunk, cout tile)
+    ("config3_level_shape", 128, 128, (2, 6, 24, 24), 1),
+]
+
+
+@pytest.mark.parametrize("name,cin,cout,dims,code", HALO_WG_CASES, ids=[c[0] for c in HALO_WG_CASES])
+def test_wgrad_halo_tile_kernel(G, monkeypatch, name, cin, cout, dims, code):
+    """conv_wgrad_halo_kernel (csrc/conv_wgrad_halo.hip: one 16-cin chunk x 128 couts x all 27 taps per block over voxel
+    tiles, X halo tile + dY tile in LDS, transposing reads) against autograd, against the one-tap kernel, run-to-run
+    bit-identical; zero padding at the volume faces comes from the DMA's zero fill (no masks): checked by the ragged cases."""
+    n, d, h, w = dims
+    lib = G.ctx().lib
+    plan = lib._dll.ctsi_wgrad_halo_plan
+    plan.restype = C.c_int
+    S, ws = C.c_int(), C.c_size_t()
+    assert plan(n, d, h, w, cin, cout, C.byref(S), C.byref(ws), None, None) == code and ws.value > 0
+    x = bf16_round(formula_input((n, cin, d, h, w), 1)).requires_grad_(True)
+    wt = bf16_round(_w((cout, cin, 3, 3, 3), 2, cin * 27)).requires_grad_(True)
+    y = F.conv3d(x, wt, None, padding=1)
+    dy = bf16_round(formula_input(tuple(y.shape), 3))
+    y.backward(dy)
+    args = (G, dy, x.detach(), (3, 3, 3), (1, 1), (1, 1, 1), 27, tuple(wt.shape), (cin * 27, 27, 1))
+    dw = _wgrad(*args)
+    e = rel_l2(dw.cpu(), wt.grad)
+    print(f"{name}: halo-tile wgrad rel-L2 {e:.2e} (S = {S.value})")
+    assert torch.isfinite(dw).all() and e <= 3e-3, name
+    assert torch.equal(dw, _wgrad(*args))
+    monkeypatch.setenv("CTSI_WGRAD_HALO", "0")
+    dw_old = _wgrad(*args)
+    assert rel_l2(dw.cpu(), dw_old.cpu()) <= 1e-3          # same products, other summation order
+    # exactness: dY = one-hot in (voxel, cout) picks X's 27 neighbours of that voxel -- incl. the zero padding at a face
+    monkeypatch.delenv("CTSI_WGRAD_HALO")
+    dy1 = torch.zeros_like(dy)
+    dy1[0, 0, 0, 0, w - 1] = 1.0                           # a corner voxel of the volume
+    dw1 = _wgrad(G, dy1, x.detach(), (3, 3, 3), (1, 1), (1, 1, 1), 27, tuple(wt.shape), (cin * 27, 27, 1)).cpu()
+    xp = F.pad(x.detach(), (1, 1, 1, 1, 1, 1))
+    expect = xp[0, :, 0:3, 0:3, w - 1:w + 2]                # (cin, 3, 3, 3) window around the corner voxel
+    assert torch.equal(dw1[0].reshape(cin, 3, 3, 3), expect) and float(dw1[1:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("name,cin,cout,dims,kind", WG_CASES, ids=[c[0] for c in WG_CASES])
@@ -168,6 +217,7 @@ def test_wgrad_mfma_16x16x32_form(G, monkeypatch, name, cin, cout, dims, kind):
     res = []
     for shape16 in ("0", "1"):
         monkeypatch.setenv("CTSI_WGRAD_SHAPE16", shape16)
+        monkeypatch.setenv("CTSI_WGRAD_HALO", "0")
         if kind == "up":
             res.append(_wgrad(G, x.detach(), dy, k, s, p, T, tuple(wt.shape), (cout * T, T, 1)))
         else:

@@ -612,9 +612,31 @@ static int wg_geometry(const ctsi_wgrad_desc* d, WgradGeom* g) {
     return CTSI_OK;
 }
 
+// conv_wgrad_halo.hip: the halo-tile weight-gradient kernel for 3x3x3 stride-1 'same' Conv3d layers
+extern "C" int ctsi_wgrad_halo_plan(int n, int d, int h, int w, int cx, int cy, int* S, size_t* ws_bytes, int* CRp, int* CGp);
+extern "C" int ctsi_wgrad_halo_launch(const void* X, const void* dY, void* part, int n, int d, int h, int w, int cx, int cx_stride,
+                                      int cy, int cy_stride, void* stream);
+
+// R = dL/dy (cr = cout), G = layer input (cg = cin) of a 3x3x3 / stride 1 / pad 1 Conv3d on equal grids: the halo-tile kernel
+// (CTSI_WGRAD_HALO=0 keeps conv_wgrad_kernel / conv_wgrad_s1_kernel: A/B timing, tests)
+static int wg_use_halo(const ctsi_wgrad_desc* d, int* S, size_t* ws, int* CRp, int* CGp) {
+    const char* e = getenv("CTSI_WGRAD_HALO");
+    if (e && atoi(e) == 0) return 0;
+    if (!(d->kd == 3 && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 && d->pd == 1 && d->ph == 1 && d->pw == 1 &&
+          d->dr == d->dg && d->hr == d->hg && d->wr == d->wg))
+        return 0;
+    const long long xb = (long long)d->n * d->dg * d->hg * d->wg * d->cg_stride * 2, yb = (long long)d->n * d->dr * d->hr * d->wr * d->cr_stride * 2;
+    if (xb >= 0x7fffffffll || yb >= 0x7fffffffll) return 0;
+    return ctsi_wgrad_halo_plan(d->n, d->dg, d->hg, d->wg, d->cg, d->cr, S, ws, CRp, CGp);
+}
+
 extern "C" size_t ctsi_wgrad_workspace_bytes(const ctsi_wgrad_desc* d) {
     WgradGeom g;
     if (wg_geometry(d, &g) != CTSI_OK) return 0;
+    {
+        size_t ws = 0;
+        if (wg_use_halo(d, nullptr, &ws, nullptr, nullptr)) return ws;
+    }
     return (size_t)g.S * g.T * (size_t)(g.tiles_r * wgk::BR) * (g.tiles_g * wgk::BG) * sizeof(float);
 }
 
@@ -630,6 +652,20 @@ extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* g
     int rc = wg_geometry(d, &g);
     if (rc != CTSI_OK) return rc;
     CTSI_CHECK_ARG(r && gt && workspace && dw, "ctsi_wgrad: null pointer");
+    {
+        int hS = 0, hCRp = 0, hCGp = 0;
+        if (wg_use_halo(d, &hS, nullptr, &hCRp, &hCGp)) {
+            rc = ctsi_wgrad_halo_launch(gt, r, workspace, d->n, d->dg, d->hg, d->wg, d->cg, d->cg_stride, d->cr, d->cr_stride, stream);
+            if (rc != CTSI_OK) return rc;
+            const long long total_h = (long long)d->cr * d->cg * 27;
+            long long rbh = (total_h + 255) / 256;
+            if (rbh > 8192) rbh = 8192;
+            hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rbh), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)workspace, dw, hS, 27, hCRp, hCGp, d->cr, d->cg, stride_r, stride_g, stride_t, scale);
+            CTSI_LAUNCH_CHECK();
+            return CTSI_OK;
+        }
+    }
     WgradParams p;
     p.R = (const bf16_t*)r;
     p.G = (const bf16_t*)gt;

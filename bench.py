@@ -314,7 +314,9 @@ def bench_train(args, pkg, E, model, ctx, dev, rank, world, dist):
             except Exception:
                 pass
             ach = wg[1] / (wg[2] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_wgrad_kernel (transposing-LDS-read MFMA weight gradient)",
+            roof = {"bound": "mfma", "kernel": "weight gradient: conv_wgrad_halo_kernel (3x3x3 layers: X halo tile + dY tile in LDS, all 27 "
+                                               "taps per block, transposing LDS reads) + conv_wgrad_kernel / conv_wgrad_s1_kernel (the other "
+                                               "layers) + their split-K reduce pass",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": wg[0],
                     "avg_launch_ms": wg[2] / wg[0],

@@ -145,13 +145,16 @@ def test_wgrad_tap_sharing_kernel(G, monkeypatch, name, cin, cout, dims, k):
 
 
 HALO_WG_CASES = [
-    # name, cin, cout, (n,d,h,w), expected tile code (1: 3x8x8, 2: 6x4x8, 3: 3x4x16)
+    # name, cin, cout, (n,d,h,w), expected tile code (1: 3x8x8, 2: 6x4x8, 3: 3x4x16, 4: 4x4x12, 5: 8x6x4)
     ("aligned_128_128", 128, 128, (1, 6, 8, 16), 1),
     ("batch2_ragged_64_192", 64, 192, (2, 5, 16, 24), 1),           # D = 5: ragged depth tiles; two cout tiles (192 of 256)
     ("cin16_cout72", 16, 72, (1, 3, 8, 8), 1),
     ("tile_3x4x16", 32, 128, (1, 3, 4, 32), 3),
     ("tile_6x4x8", 32, 64, (1, 6, 4, 16), 2),
     ("ragged_planes_12x12", 64, 128, (1, 6, 12, 12), 2),            # 12-wide planes: W tiles of 8 cover 16 (75 %)
+    ("tile_4x4x12", 64, 128, (1, 8, 12, 12), 4),                     # 12-wide planes at 100 %: blocks of 4 voxels straddle lines
+    ("tile_4x4x12_w24_batch2", 32, 64, (2, 4, 8, 24), 4),
+    ("tile_8x6x4_6wide_planes", 128, 128, (2, 16, 6, 6), 5),        # the 6 x 6 level of config 3
     ("multi_slice_256_256", 256, 256, (1, 12, 16, 16), 1),          # several voxel-tile slices per (chunk, cout tile)
     ("config3_level_shape", 128, 128, (2, 6, 24, 24), 1),
 ]

@@ -50,7 +50,10 @@ struct WhCfg {
     static constexpr int NV = TD * TH * TW;
     static constexpr int KS = NV / 32;                    // K-steps (32 voxels) per tile
     static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
-    static constexpr int HWP = TW == 8 ? 12 : 20;         // padded w-stride (rows): HWP * 32 B = 128 (mod 256)
+    // padded w-stride of the halo tile in rows: a multiple of 4 whose quarter is ODD, so that the 128-byte blocks (4 voxels x
+    // 32 B) of two consecutive voxel blocks -- same line or across a line / slice boundary -- fall into different halves of the
+    // 256-byte bank period (see the k-group mapping below)
+    static constexpr int HWP = ((HW + 3) / 4) % 2 ? ((HW + 3) / 4) * 4 : ((HW + 3) / 4 + 1) * 4;
     static constexpr int HROWS = HD * HH * HWP;
     static constexpr int XPIECES = (HROWS + 31) / 32;
     static constexpr int XBYTES = XPIECES * 1024;
@@ -60,25 +63,21 @@ struct WhCfg {
     static constexpr int NTH = 512, NWAVE = 8;
     static constexpr int XPW = (XPIECES + NWAVE - 1) / NWAVE;   // X pieces per wave
     static constexpr int DPW = DYPIECES / NWAVE;                // dY pieces per wave
-    static_assert(NV % 32 == 0 && (TW == 8 || TW == 16) && (32 / TW) <= TH && TH % (32 / TW) == 0 && LDS_BYTES <= 160 * 1024 &&
-                      DYPIECES % NWAVE == 0, "unsupported tile");
-    // tile voxel (d, h) of the FIRST line of K-step s (a step = 32 / TW whole lines)
-    static constexpr int LPS = 32 / TW;
-    static constexpr int step_d(int s) { return (s * LPS) / TH; }
-    static constexpr int step_h(int s) { return (s * LPS) % TH; }
-    static constexpr int step_row(int s) { return (step_d(s) * HH + step_h(s)) * HWP; }
+    static constexpr int NBW = TW / 4;                          // 4-voxel blocks per w-line
+    static_assert(NV % 32 == 0 && TW % 4 == 0 && LDS_BYTES <= 160 * 1024 && DYPIECES % NWAVE == 0 && (HWP / 4) % 2 == 1,
+                  "unsupported tile");
 };
 
-// k-group kg (8 of the step's 32 voxels) -> (line inside the step, first w): TW = 8: line kg; TW = 16: line kg & 1, w 8 (kg >> 1)
-template <int TW>
-__device__ __forceinline__ void wh_kgroup(int kg, int* line, int* w0) {
-    if (TW == 8) {
-        *line = kg;
-        *w0 = 0;
-    } else {
-        *line = kg & 1;
-        *w0 = 8 * (kg >> 1);
-    }
+// K position (step s, k-group kg, half e, 0..3) -> tile voxel.  The tile's voxels, w fastest, form NV / 4 blocks of 4 voxels
+// along w; step s owns blocks 8 s .. 8 s + 7, and (kg, e) takes block 8 s + 4 e + kg: the two k-groups a transposing read serves
+// together (kg, kg + 1) hold CONSECUTIVE blocks, whose halo rows are 128 B apart modulo 256 by the choice of HWP.
+template <int TH, int TW>
+__device__ __forceinline__ void wh_block(int s, int kg, int e, int* d, int* h, int* w) {
+    const int b = 8 * s + 4 * e + kg;
+    const int line = b / (TW / 4);
+    *w = 4 * (b - line * (TW / 4));
+    *d = line / TH;
+    *h = line - *d * TH;
 }
 
 template <int TD, int TH, int TW>
@@ -87,6 +86,7 @@ conv_wgrad_halo_kernel(const WgradHaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = WhCfg<TD, TH, TW>;
     constexpr int KS = Cfg::KS, HH = Cfg::HH, HW = Cfg::HW, HWP = Cfg::HWP, HROWS = Cfg::HROWS, XPIECES = Cfg::XPIECES;
+    static_assert(Cfg::TD == TD && Cfg::TH == TH && Cfg::TW == TW, "");
     constexpr int XBYTES = Cfg::XBYTES, STAGE = Cfg::STAGE, XPW = Cfg::XPW, DPW = Cfg::DPW, NWAVE = Cfg::NWAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;
@@ -123,13 +123,12 @@ conv_wgrad_halo_kernel(const WgradHaloParams p) {
     {
         const int pos = lane >> 1;
         const int kg = (pos >> 2) & 3, e = pos >> 4, q = pos & 3;
-        int line, w0;
-        wh_kgroup<TW>(kg, &line, &w0);
 #pragma unroll
         for (int i = 0; i < DPW; ++i) {
             const int s = (wave + NWAVE * i) % KS;
-            const int L = s * Cfg::LPS + line;
-            yc[i] = (L / TH) | ((L % TH) << 8) | ((w0 + 4 * e + q) << 16);
+            int d, h, w;
+            wh_block<TH, TW>(s, kg, e, &d, &h, &w);
+            yc[i] = d | (h << 8) | ((w + q) << 16);
         }
     }
     const unsigned half16 = (unsigned)((lane & 1) * 16);
@@ -178,9 +177,15 @@ conv_wgrad_halo_kernel(const WgradHaloParams p) {
     // lane addresses row q = r16 >> 2, 8-byte piece pp = r16 & 3 and receives channel r16's 4 consecutive voxels
     const int r16 = lane & 15, kg = lane >> 4;
     const int q = r16 >> 2, pp = r16 & 3;
-    int kline, kw0;
-    wh_kgroup<TW>(kg, &kline, &kw0);
-    const unsigned a_lane = (unsigned)((kline * HWP + kw0 + q) * 32 + pp * 8);        // + step_row, tap row, 128 e
+    unsigned a_step[KS][2];                                  // halo byte offset of this lane's row for (step, e), tap (0, 0, 0)
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+        for (int e_ = 0; e_ < 2; ++e_) {
+            int d, h, w;
+            wh_block<TH, TW>(s_, kg, e_, &d, &h, &w);
+            a_step[s_][e_] = (unsigned)(((d * HH + h) * HWP + w + q) * 32 + pp * 8);
+        }
     const unsigned b_lane = (unsigned)(XBYTES + (kg * 4 + q) * 32 + pp * 8);          // + (j KS + s) 1024, 512 e
 
     f32x4 acc[7][4];
@@ -197,8 +202,8 @@ conv_wgrad_halo_kernel(const WgradHaloParams p) {
         int tap = mg + 4 * i_;
         tap = tap < 27 ? tap : 26;                       // (tap group 3's last slot repeats tap 26; its tile is not stored)
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-        const unsigned a = sb + a_lane + (unsigned)((Cfg::step_row(s_) + (kd * HH + kh) * HWP + kw) * 32);
-        const wh_s16x4 a0 = wh_tr_read(a), a1 = wh_tr_read(a + 128);
+        const unsigned toff = (unsigned)(((kd * HH + kh) * HWP + kw) * 32);
+        const wh_s16x4 a0 = wh_tr_read(sb + a_step[s_][0] + toff), a1 = wh_tr_read(sb + a_step[s_][1] + toff);
         return __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     auto load_b = [&](unsigned sb, int s_, int j) -> bf16x8 {
@@ -270,19 +275,19 @@ conv_wgrad_halo_kernel(const WgradHaloParams p) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
-// tile choice: 3x8x8 (planes whose H and W are multiples of 8), 6x4x8 (W multiple of 8, H of 4), 3x4x16; the useful fraction of
-// the tile voxels must be >= 0.7.  Returns 0 when the layer does not qualify (the caller falls back to conv_wgrad.hip's kernels).
+// tile choice among 3x8x8, 6x4x8, 3x4x16, 4x4x12 (12- / 24-wide planes) and 8x6x4 (6-wide planes): the one with the largest
+// useful fraction of its 192 voxels, which must be >= 0.7.  Returns 0 when the layer does not qualify (the caller falls back to conv_wgrad.hip's kernels).
 struct WhPlan {
-    int code;      // 1: 3x8x8, 2: 6x4x8, 3: 3x4x16
+    int code;      // 1: 3x8x8, 2: 6x4x8, 3: 3x4x16, 4: 4x4x12, 5: 8x6x4
     int td, th, tw, tilesD, tilesH, tilesW, ntiles, nchunks, ncot, S, tps, CRp, CGp;
 };
 
 static int wh_plan(int n, int d, int h, int w, int cx, int cy, WhPlan* o) {
     if (cx % 16 != 0 || cy % 8 != 0) return 0;
-    const int cand[3][4] = {{1, 3, 8, 8}, {2, 6, 4, 8}, {3, 3, 4, 16}};
+    const int cand[5][4] = {{1, 3, 8, 8}, {2, 6, 4, 8}, {3, 3, 4, 16}, {4, 4, 4, 12}, {5, 8, 6, 4}};
     double best = 0.0;
     int bi = -1;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 5; ++i) {
         const int td = cand[i][1], th = cand[i][2], tw = cand[i][3];
         const double tiles = (double)((d + td - 1) / td) * ((h + th - 1) / th) * ((w + tw - 1) / tw);
         const double useful = (double)d * h * w / (tiles * td * th * tw);
@@ -356,7 +361,9 @@ extern "C" int ctsi_wgrad_halo_launch(const void* X, const void* dY, void* part,
     const int blocks = pl.nchunks * pl.ncot * pl.S;
     if (pl.code == 1) wh_launch<3, 8, 8>(p, blocks, (hipStream_t)stream);
     else if (pl.code == 2) wh_launch<6, 4, 8>(p, blocks, (hipStream_t)stream);
-    else wh_launch<3, 4, 16>(p, blocks, (hipStream_t)stream);
+    else if (pl.code == 3) wh_launch<3, 4, 16>(p, blocks, (hipStream_t)stream);
+    else if (pl.code == 4) wh_launch<4, 4, 12>(p, blocks, (hipStream_t)stream);
+    else wh_launch<8, 6, 4>(p, blocks, (hipStream_t)stream);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

@@ -2,7 +2,7 @@ set -e
 export TMPDIR=/tmp
 O=gpurun_out/r3
 mkdir -p $O
-C=8067e2c
+C=843e89d
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train2 -o train -- python3 bench.py --mode train --steps 5 --warmup 2 --no-roofline > $O/prof_train2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_tfetch2 -o fetch -- python3 tools/profile_train.py --repeats 1 > $O/pmc_tfetch2.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_twrite2 -o write -- python3 tools/profile_train.py --repeats 1 > $O/pmc_twrite2.log 2>&1

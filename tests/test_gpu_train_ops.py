@@ -182,6 +182,9 @@ def test_wgrad_halo_tile_kernel(G, monkeypatch, name, cin, cout, dims, code):
     print(f"{name}: halo-tile wgrad rel-L2 {e:.2e} (S = {S.value})")
     assert torch.isfinite(dw).all() and e <= 3e-3, name
     assert torch.equal(dw, _wgrad(*args))
+    monkeypatch.setenv("CTSI_WGRAD_REDUCE_T", "0")         # the one-thread-per-output reduce pass: same sums, other order
+    assert rel_l2(dw.cpu(), _wgrad(*args).cpu()) <= 1e-6
+    monkeypatch.delenv("CTSI_WGRAD_REDUCE_T")
     monkeypatch.setenv("CTSI_WGRAD_HALO", "0")
     dw_old = _wgrad(*args)
     assert rel_l2(dw.cpu(), dw_old.cpu()) <= 1e-3          # same products, other summation order

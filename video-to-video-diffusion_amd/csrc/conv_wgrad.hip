@@ -546,6 +546,76 @@ conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
     }
 }
 
+// The same reduction for the PyTorch weight layout (st == 1, sg == T: the T taps of one (cr, cg) pair are contiguous in dw),
+// transposed through LDS: the kernel above reads coalesced but writes every 4-byte result into its own 108-byte-strided line
+// and ran at ~1 TB/s (53.8 us per launch, 88 launches = 4.7 ms of a config-3 micro-step, profiles/r03_train_kernel_stats.csv).
+// One block = one cr x 64 cg x all T taps: 16-byte loads down the slices (4 independent accumulators, fixed order: slices
+// k = 0, 4, 8, .. / 1, 5, .. / 2, .. / 3, .. then (a0 + a1) + (a2 + a3)), the T x 64 sums staged in LDS, written out as one
+// contiguous run of 64 T floats.
+template <int TMAX>
+__global__ void __launch_bounds__(256)
+conv_wgrad_reduce_t_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T, int CRp, int CGp, int CR,
+                           int CG, long long sr, float scale) {
+    __shared__ float s_t[TMAX][64 + 1];
+    const int tid = threadIdx.x;
+    const int cgt = blockIdx.x, cr = blockIdx.y;
+    const int cg0 = cgt * 64;
+    const size_t slice = (size_t)T * CRp * CGp;
+    const int c4 = (tid & 15) * 4;                                     // 4 consecutive cg of this thread
+    for (int t = tid >> 4; t < T; t += 16) {
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        if (cg0 + c4 < CGp) {                                          // (CGp is a multiple of 16; rows beyond CG hold zeros / are not written)
+            const float* src = part + ((size_t)t * CRp + cr) * CGp + cg0 + c4;
+            int k = 0;
+            for (; k + 3 < S; k += 4) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)k * slice);
+                const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(k + 1) * slice);
+                const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(k + 2) * slice);
+                const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(k + 3) * slice);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+            }
+            for (int u = 0; k < S; ++k, ++u) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * slice);
+                float4& a = u == 0 ? a0 : (u == 1 ? a1 : a2);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        }
+        s_t[t][c4 + 0] = ((a0.x + a1.x) + (a2.x + a3.x)) * scale;
+        s_t[t][c4 + 1] = ((a0.y + a1.y) + (a2.y + a3.y)) * scale;
+        s_t[t][c4 + 2] = ((a0.z + a1.z) + (a2.z + a3.z)) * scale;
+        s_t[t][c4 + 3] = ((a0.w + a1.w) + (a2.w + a3.w)) * scale;
+    }
+    __syncthreads();
+    const int ncg = min(64, CG - cg0);
+    float* dst = dw + cr * sr + (long long)cg0 * T;
+    for (int o = tid; o < ncg * T; o += 256) {
+        const int cgl = o / T, t = o - cgl * T;
+        dst[o] = s_t[t][cgl];
+    }
+}
+
+// reduce pass of ctsi_wgrad (both kernel families): picks the transposing form for the PyTorch layout
+static void wg_reduce(const float* part, float* dw, int S, int T, int CRp, int CGp, int CR, int CG, long long sr, long long sg,
+                      long long st, float scale, hipStream_t stream) {
+    const char* e = getenv("CTSI_WGRAD_REDUCE_T");   // "0": the one-thread-per-output form (A/B timing, tests)
+    if (st == 1 && sg == T && (CGp % 16) == 0 && T <= 48 && !(e && atoi(e) == 0)) {
+        const dim3 grid((CG + 63) / 64, CR);
+        if (T <= 27)
+            hipLaunchKernelGGL(conv_wgrad_reduce_t_kernel<27>, grid, dim3(256), 0, stream, part, dw, S, T, CRp, CGp, CR, CG, sr, scale);
+        else
+            hipLaunchKernelGGL(conv_wgrad_reduce_t_kernel<48>, grid, dim3(256), 0, stream, part, dw, S, T, CRp, CGp, CR, CG, sr, scale);
+        return;
+    }
+    const long long total = (long long)CR * CG * T;
+    long long rb = (total + 255) / 256;
+    if (rb > 8192) rb = 8192;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, part, dw, S, T, CRp, CGp, CR, CG, sr, sg,
+                       st, scale);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 static void wg_magic(unsigned d, unsigned* m, int* sh) {
     int s = 0;
@@ -657,11 +727,8 @@ extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* g
         if (wg_use_halo(d, &hS, nullptr, &hCRp, &hCGp)) {
             rc = ctsi_wgrad_halo_launch(gt, r, workspace, d->n, d->dg, d->hg, d->wg, d->cg, d->cg_stride, d->cr, d->cr_stride, stream);
             if (rc != CTSI_OK) return rc;
-            const long long total_h = (long long)d->cr * d->cg * 27;
-            long long rbh = (total_h + 255) / 256;
-            if (rbh > 8192) rbh = 8192;
-            hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rbh), dim3(256), 0, (hipStream_t)stream,
-                               (const float*)workspace, dw, hS, 27, hCRp, hCGp, d->cr, d->cg, stride_r, stride_g, stride_t, scale);
+            wg_reduce((const float*)workspace, dw, hS, 27, hCRp, hCGp, d->cr, d->cg, stride_r, stride_g, stride_t, scale,
+                      (hipStream_t)stream);
             CTSI_LAUNCH_CHECK();
             return CTSI_OK;
         }
@@ -708,12 +775,8 @@ extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* g
                                (hipStream_t)stream, p);
     }
     CTSI_LAUNCH_CHECK();
-    const long long total = (long long)d->cr * d->cg * g.T;
-    long long rb = (total + 255) / 256;
-    if (rb > 8192) rb = 8192;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)workspace, dw, g.S, g.T, g.tiles_r * wgk::BR, g.tiles_g * wgk::BG, d->cr, d->cg,
-                       stride_r, stride_g, stride_t, scale);
+    wg_reduce((const float*)workspace, dw, g.S, g.T, g.tiles_r * wgk::BR, g.tiles_g * wgk::BG, d->cr, d->cg, stride_r, stride_g,
+              stride_t, scale, (hipStream_t)stream);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

@@ -303,3 +303,30 @@ def test_full_width_training_step_vs_oracle_autograd(pkg):
     # bf16 storage / fp32 accumulation through ~110 layers forward and back; the tiny-model tests hold the same quantity
     # against the reference's own bf16-autocast error (3-4e-2 there)
     assert errs[0][0] <= 0.15 and errs[len(errs) // 2][0] <= 6e-2
+
+
+def test_ms_ssim_branch_behaves_like_the_reference_without_the_package(pkg, capsys):
+    """GaussianDiffusion.training_loss(use_ssim=True, ...) (models/diffusion.py:204-240): `pytorch_msssim` is a third-party
+    package (requirements.txt:24) that neither this image nor the reference's importable environment has; the reference then
+    prints a warning and returns the MSE loss unchanged.  Same here, word for word; without `vae` / `v_gt` / a positive
+    weight the branch is not entered at all."""
+    try:
+        import pytorch_msssim  # noqa: F401
+        pytest.skip("pytorch_msssim is installed: the fallback branch cannot be observed")
+    except ImportError:
+        pass
+    model, sd, cfg = tiny_model_sd(pkg)
+    model.to(DEV)
+    z0, cond = formula_input((2, 8, 4, 4, 4), 51).to(DEV), formula_input((2, 8, 4, 4, 4), 52).to(DEV)
+    t, nz = torch.tensor([37, 812], device=DEV), formula_noise(-1, (2, 8, 4, 4, 4)).to(DEV)
+    v_gt = formula_input((2, 1, 4, 16, 16), 53).clamp(-1, 1).to(DEV)
+    base, d0 = model.diffusion.training_loss(model.unet, z0, cond, t=t, noise=nz)
+    capsys.readouterr()
+    l1, d1 = model.diffusion.training_loss(model.unet, z0, cond, vae=model.vae, v_gt=v_gt, use_ssim=True, ssim_weight=0.3,
+                                           t=t, noise=nz)
+    out = capsys.readouterr().out
+    assert "Warning: pytorch-msssim not installed. Falling back to MSE-only loss." in out
+    assert float(l1) == float(base) and d1 == d0 and "ssim" not in d1
+    l2, _ = model.diffusion.training_loss(model.unet, z0, cond, vae=model.vae, v_gt=v_gt, use_ssim=True, ssim_weight=0.0,
+                                          t=t, noise=nz)
+    assert capsys.readouterr().out == "" and float(l2) == float(base)

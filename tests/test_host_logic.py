@@ -138,6 +138,51 @@ def test_no_cpu_fallback(pkg):
         m(x, x)
     with pytest.raises(pkg.CtsiError):
         m.diffusion.training_loss(m.unet, torch.zeros(1, 4, 2, 4, 4), torch.zeros(1, 4, 2, 4, 4))
+    # single reverse steps (models/diffusion.py:249-338) and the optimizer step: HIP engine only as well
+    z = torch.zeros(2, 8, 2, 4, 4)
+    tt = torch.tensor([5, 700])
+    with pytest.raises(pkg.CtsiError):
+        m.diffusion._predict_z_0_from_noise(z, tt, z)
+    with pytest.raises(pkg.CtsiError):
+        m.diffusion.p_mean_variance(lambda a, b, c: a, z, tt, z)
+    with pytest.raises(pkg.CtsiError):
+        m.diffusion.p_sample(lambda a, b, c: a, z, tt, z, clip_denoised=False)
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    for cls in (pkg.FusedAdamW, pkg.FusedAdam):
+        opt = cls([dict(params=[p], lr=1e-3, name="g")], weight_decay=0.01)
+        assert opt.param_groups[0]["name"] == "g" and opt.defaults["betas"] == (0.9, 0.999)
+        with pytest.raises(pkg.CtsiError):
+            opt.step()
+    with pytest.raises(pkg.CtsiError):
+        pkg.FusedAdamW([p], amsgrad=True)
+    with pytest.raises(ValueError):
+        pkg.FusedAdamW([p], lr=-1.0)
+
+
+def test_fused_optimizer_step_counters_follow_torch(pkg, monkeypatch):
+    """Host bookkeeping of optim.FusedAdamW without a GPU: per-parameter step counts like torch's (a parameter without a
+    gradient skips the step), one shared counter per group in the steady state, un-aliased counters in state_dict()."""
+    O = importlib.import_module("video-to-video-diffusion_amd.optim")
+    ps = [torch.nn.Parameter(torch.zeros(4)) for _ in range(3)]
+    opt = O.FusedAdamW([dict(params=ps[:2], lr=1e-3), dict(params=ps[2:], lr=1e-4)])
+    for p in ps:                                         # (pretend they are device tensors: only the bookkeeping runs)
+        opt._init_state(p)
+    for p in ps:
+        p.grad = torch.ones(4)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    e, rows = opt._hyper_rows()
+    assert len(e) == 3 and len(rows) == 2 and [float(opt.state[p]["step"]) for p in ps] == [1.0, 1.0, 1.0]
+    assert opt.state[ps[0]]["step"] is opt.state[ps[1]]["step"]          # shared inside the group
+    ps[1].grad = None                                                      # sits this step out
+    e, rows = opt._hyper_rows()
+    assert [float(opt.state[p]["step"]) for p in ps] == [2.0, 1.0, 2.0] and len(e) == 2
+    ps[1].grad = torch.ones(4)
+    e, rows = opt._hyper_rows()                                            # two step counts in group 0 -> two rows for it
+    assert [float(opt.state[p]["step"]) for p in ps] == [3.0, 2.0, 3.0] and len(rows) == 3
+    sd = opt.state_dict()
+    assert sd["state"][0]["step"] is not sd["state"][1]["step"]
+    assert {float(v["step"]) for v in sd["state"].values()} == {3.0, 2.0}
 
 
 def test_product_does_not_import_oracle():

@@ -8,6 +8,7 @@ ctsi_ddpm_step kernel; single steps with per-sample timesteps (`p_mean_variance`
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import torch
@@ -167,8 +168,9 @@ class GaussianDiffusion(nn.Module):
         t ~ randint(0, T, (B,)) and noise ~ randn_like(z_0) are drawn with torch's generator in the reference's
         order; `t=` / `noise=` (additive kwargs) inject them instead (tests).  The three normalisations of the
         reference (no mask; mask with equal valid counts; mask with per-sample counts) are folded into one
-        per-sample factor.  The optional MS-SSIM term needs `pytorch_msssim` and a decode inside the loss; the
-        reference falls back to MSE-only when that import fails, and so does this engine, always."""
+        per-sample factor.  The optional MS-SSIM term (a gradient-free logging term: the reference decodes under no_grad)
+        needs the third-party `pytorch_msssim`; without it the reference warns and returns the MSE loss, and so does this
+        engine (see the end of the function)."""
         from .train_engine import UNetTrainProgram, train_step
         from .engine import Ctx, cached_program
         if not z_0.is_cuda:
@@ -202,5 +204,33 @@ class GaussianDiffusion(nn.Module):
             prog.set_diffusion(self)
         loss = train_step(prog, z_0.detach().float(), c.detach().float(), t, noise.float(), norm, m)
         loss_dict = {'mse': loss.item()}
+        # Optional MS-SSIM term (diffusion.py:204-240).  The reference decodes the predicted z_0 under torch.no_grad(), so the
+        # term carries NO gradient: total = (1 - w) * mse + w * (1 - ms_ssim) scales the MSE gradient by (1 - w) and adds a
+        # constant.  ms_ssim itself is `pytorch_msssim.ms_ssim` (requirements.txt:24, `pytorch-msssim>=1.0.0`), a third-party
+        # package; where it is absent the reference prints the warning below and returns the MSE loss -- so does this
+        # engine (model.forward never enables the term: models/model.py:218-219).
+        if use_ssim and ssim_weight > 0.0 and vae is not None and v_gt is not None:
+            try:
+                from pytorch_msssim import ms_ssim
+                with torch.no_grad():
+                    z_t, _ = self.q_sample(z_0.detach().float(), t, noise.float())
+                    eps = torch.empty((B, L, d, h, w), dtype=torch.float32, device=device)
+                    with ctx.scope():
+                        ctx.lib.ndhwc_f32_to_ncdhw_f32(C.c_void_p(prog.eps.data_ptr()), C.c_void_p(eps.data_ptr()), B, L, d, h,
+                                                       w, ctx.sptr)
+                    v_pred = vae.decode(self._predict_z_0_from_noise(z_t, t, eps))
+                    terms = []
+                    for i in range(v_gt.shape[2]):
+                        terms.append(1.0 - ms_ssim((v_pred[:, :, i] + 1.0) / 2.0, (v_gt[:, :, i].float() + 1.0) / 2.0,
+                                                   data_range=1.0, size_average=True))
+                    loss_ssim = torch.stack(terms).mean()
+                loss_dict['ssim'] = loss_ssim.item()
+                total = (1.0 - ssim_weight) * loss + ssim_weight * loss_ssim
+                loss_dict['total'] = total.item()
+                return total, loss_dict
+            except ImportError:
+                print("Warning: pytorch-msssim not installed. Falling back to MSE-only loss.")
+            except Exception as e:
+                print(f"Warning: MS-SSIM calculation failed: {e}. Using MSE-only loss.")
         loss_dict['total'] = loss_dict['mse']
         return loss, loss_dict

@@ -117,3 +117,32 @@ def test_fast_repack_equals_generic_repack_and_training_continues(pkg):
     assert losses[2][0] < losses[0][0]              # and the optimizer optimizes
     for p1, p2 in zip(model.unet.parameters(), twin.unet.parameters()):
         assert rel_l2(p1.detach(), p2.detach()) < 5e-2
+
+
+def test_fused_optimizer_under_gradscaler_and_lr_scheduler(pkg):
+    """The reference's loop steps its optimizer through a GradScaler under AMP (training/trainer.py:237-247) and drives the
+    learning rate with a torch scheduler: both work on the drop-in unchanged, and match torch.optim.AdamW under the same."""
+    ours, ref = _params(300)[:4], _params(300)[:4]
+    o1, o2 = pkg.FusedAdamW(ours, lr=1e-2, weight_decay=0.02), torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.02)
+    s1 = torch.optim.lr_scheduler.StepLR(o1, step_size=1, gamma=0.5)
+    s2 = torch.optim.lr_scheduler.StepLR(o2, step_size=1, gamma=0.5)
+    g1, g2 = torch.amp.GradScaler("cuda", init_scale=1024.0), torch.amp.GradScaler("cuda", init_scale=1024.0)
+    for step in range(3):
+        for ps, opt, sc, sch in ((ours, o1, g1, s1), (ref, o2, g2, s2)):
+            loss = sum((p * formula_input(tuple(p.shape), 700 + 10 * step + i).to(DEV)).sum() for i, p in enumerate(ps))
+            opt.zero_grad(set_to_none=True)
+            sc.scale(loss).backward()
+            sc.step(opt)
+            sc.update()
+            sch.step()
+    torch.cuda.synchronize()
+    assert o1.param_groups[0]["lr"] == pytest.approx(o2.param_groups[0]["lr"]) == pytest.approx(1e-2 * 0.125)
+    for a, b in zip(ours, ref):
+        assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * float(b.detach().abs().max())
+    # an overflowing step is skipped by the scaler for both
+    ours[0].grad = torch.full_like(ours[0], float("inf"))
+    before = ours[0].detach().clone()
+    g1._per_optimizer_states.clear()
+    g1.unscale_(o1)
+    g1.step(o1)
+    assert torch.equal(ours[0].detach(), before)

@@ -1,8 +1,10 @@
+# Evidence collection of round 3 (run on the GPU box through gpurun): the bench command under rocprofv3 --kernel-trace --stats and the
+# separate --pmc passes; the summaries under gpurun_out/r3 were copied into profiles/ by hand.
 set -e
 export TMPDIR=/tmp
 O=gpurun_out/r3
 mkdir -p $O
-C=${CTSI_COMMIT:-41099d4+}
+C=${CTSI_COMMIT:-unknown}   # git is not available on the GPU box: pass the short hash
 # 1. the bench command under rocprofv3 --kernel-trace --stats (same command as the bench log next to it)
 python3 bench.py --steps 20 --warmup 5 > $O/bench_v3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-volume > $O/prof_bench.log 2>&1

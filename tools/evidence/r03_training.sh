@@ -1,8 +1,10 @@
+# Evidence collection of round 3 (run on the GPU box through gpurun): the bench command under rocprofv3 --kernel-trace --stats and the
+# separate --pmc passes; the summaries under gpurun_out/r3 were copied into profiles/ by hand.
 set -e
 export TMPDIR=/tmp
 O=gpurun_out/r3
 mkdir -p $O
-C=843e89d
+C=${CTSI_COMMIT:-unknown}   # git is not available on the GPU box: pass the short hash
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train2 -o train -- python3 bench.py --mode train --steps 5 --warmup 2 --no-roofline > $O/prof_train2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_tfetch2 -o fetch -- python3 tools/profile_train.py --repeats 1 > $O/pmc_tfetch2.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_twrite2 -o write -- python3 tools/profile_train.py --repeats 1 > $O/pmc_twrite2.log 2>&1

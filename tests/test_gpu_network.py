@@ -95,6 +95,22 @@ def _bf16_autocast_reference(fn):
         return fn().float()
 
 
+def test_vae_on_sizes_that_are_not_multiples_of_four(pkg):
+    """Planes the stride-2 stages do not divide evenly (the reference's Conv3d / ConvTranspose3d floor and double them):
+    encode (1,1,3,18,22) -> latent (.,.,3,4,5) -> decode (.,.,3,16,20), against the oracle; odd planes take the gather
+    kernel instead of the parity-sub-grid Downsample form."""
+    vae = pkg.VideoVAE(in_channels=1, latent_dim=8, base_channels=16, scaling_factor=0.5)
+    sd = load_formula(vae, 10)
+    vae.to(DEV)
+    x = formula_input((1, 1, 3, 18, 22), 14)
+    z = vae.encode(x.to(DEV)).cpu()
+    z_ref = R.vae_encode(sd, x, 0.5)
+    assert tuple(z.shape) == tuple(z_ref.shape) == (1, 8, 3, 4, 5) and rel_l2(z, z_ref) < NET_TOL
+    y = vae.decode(z_ref.to(DEV)).cpu()
+    y_ref = R.vae_decode(sd, z_ref, 0.5)
+    assert tuple(y.shape) == tuple(y_ref.shape) == (1, 1, 3, 16, 20) and rel_l2(y, y_ref) < NET_TOL
+
+
 def test_ddim_trajectory_and_psnr_criterion(golden, pkg):
     model, sd, cfg = tiny_model_sd(pkg)
     model.to(DEV)

@@ -47,6 +47,8 @@ CONV_CASES = [
     ("down_3x4x4_64", 64, 0, 64, (1, 3, 8, 12), "down"),
     ("down_small_cin32", 32, 0, 32, (1, 2, 6, 10), "down"),
     ("down_128_odd", 128, 0, 128, (2, 3, 10, 6), "down"),
+    ("down_64_odd_planes_7x9", 64, 0, 64, (1, 3, 7, 9), "down"),      # odd planes: not the parity-sub-grid form (gather kernel)
+    ("down_128_cout32", 128, 0, 32, (1, 2, 8, 8), "down"),            # few couts: gather kernel
     ("convT_64", 64, 0, 64, (1, 3, 4, 5), "up"),
     ("convT_small_cin32", 32, 0, 32, (1, 2, 3, 6), "up"),
     ("convT_256_128", 256, 0, 128, (2, 2, 5, 4), "up"),

@@ -218,6 +218,66 @@ def test_downsample_conv_on_halo_tile_kernel(G, monkeypatch, name, cin, cout, di
         assert torch.equal(y3[:, :m], x[:, :m, :, 1::2, 0::2])
 
 
+GSPLIT_CASES = [
+    # name, c1, c2, cout, (n,d,h,w), k, forced split (None: the plan's own choice)
+    ("level_6x6_256_256", 256, 0, 256, (1, 8, 6, 6), 3, None),
+    ("level_6x6_concat_512+512_to_512", 512, 512, 512, (1, 6, 6, 6), 3, None),
+    ("forced_3_two_sources_ragged", 64, 64, 128, (1, 5, 7, 9), 3, "3"),
+    ("forced_8_deep_k", 512, 0, 128, (1, 3, 6, 6), 3, "8"),
+    ("forced_2_1x1x1_k1024", 1024, 0, 128, (1, 4, 6, 6), 1, "2"),
+]
+
+
+@pytest.mark.parametrize("name,c1,c2,cout,dims,k,force", GSPLIT_CASES, ids=[c[0] for c in GSPLIT_CASES])
+def test_gather_kernel_split_k(G, monkeypatch, name, c1, c2, cout, dims, k, force):
+    """S-way split-K of the gather kernel (few-block launches with a deep K loop: the coarsest levels of a single 192^2
+    patch): parked accumulators + ticket, summed in split order by whichever block comes last -- against F.conv3d, against
+    the unsplit kernel, the GroupNorm column sums, bit-identical from launch to launch and under hipGraph replay."""
+    import ctypes as C
+    import importlib
+    E = importlib.import_module("video-to-video-diffusion_amd.engine")
+    n, d, h, w = dims
+    x1 = bf16_round(formula_input((n, c1, d, h, w), 1))
+    x2 = bf16_round(formula_input((n, c2, d, h, w), 2)) if c2 else None
+    x = torch.cat([x1, x2], 1) if c2 else x1
+    wt = bf16_round(_w((cout, c1 + c2, k, k, k), 3))
+    b = formula_input((cout,), 4) * 0.1
+    ref = F.conv3d(x, wt, b, padding=k // 2)
+    monkeypatch.setenv("CTSI_CONV_NO_HALO3", "1")
+    if force:
+        monkeypatch.setenv("CTSI_CONV_GSPLIT", force)
+    c = G.ctx()
+    with c.scope():
+        prog = E.Program(c)
+        a1 = G.to_act(prog, x1)
+        a2 = G.to_act(prog, x2) if x2 is not None else None
+        prog.zero_gn_op()
+        y, st = prog.conv("c", lambda: wt, lambda: b, a1, a2, k=(k, k, k), p=(k // 2,) * 3, cout=cout, want_stats=True)
+        slot = prog.gn_finalize(y, 8, st)
+        prog.finalize_layout()
+        assert prog.op_meta[0][2].endswith("s"), prog.op_meta[0][2]          # the split-K form was selected
+        outs = []
+        for _ in range(3):
+            prog.run()
+            outs.append((G.from_act(prog, y).clone(), prog._gn_sums[slot:slot + n * 16].clone()))
+        prog.capture()
+        for _ in range(2):
+            prog.launch()
+            outs.append((G.from_act(prog, y).clone(), prog._gn_sums[slot:slot + n * 16].clone()))
+    torch.cuda.synchronize()
+    assert rel_l2(outs[0][0].cpu(), ref) < CONV_TOL, name
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+    rg = ref.reshape(n, 8, -1).double()
+    sums = outs[0][1].reshape(n, 8, 2).cpu()
+    assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+    assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
+    monkeypatch.setenv("CTSI_CONV_GSPLIT", "0")
+    y0, _ = G.run_conv(x1, x2, wt, b, k=(k, k, k), p=(k // 2,) * 3)
+    assert float((outs[0][0].cpu() - y0).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    E.check_device_errors(c)
+
+
 def test_split_k_conv_is_bit_stable_and_matches(G, monkeypatch):
     """2-way split-K form of the k32 kernel (conv3_halo_k32_kernel<..., SK>): the benchmark's 16-wide level shape class
     (few voxels, 512 input channels, several n-tiles, ragged edges, batch 2) -- same result whichever half finishes first

@@ -66,6 +66,12 @@ struct ConvKParams {
     int gn_groups, gn_silu;
     float gn_eps;
     double gn_count;
+    // S-way split-K (launches of a few dozen blocks with a deep K loop: the 6 x 6 / 12 x 12 levels of a single 192^2 patch):
+    // every (m-tile, n-tile) runs as `ksplit` blocks that each walk 1 / ksplit of the K-steps and park their fp32 accumulators;
+    // the block that takes the last ticket sums the parked tiles in split order and runs the epilogue
+    int ksplit;
+    float* sk_ws;       // [tile][split][register][thread] fp32
+    int* sk_sync;       // [tile] ticket counters (zero before the first launch; the last block resets its tile's)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -109,7 +115,10 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     const int wm = wave / WN, wn = wave % WN;
 
     // ---- block decode ---------------------------------------------------------------------
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int split = bid % nsplit;                        // (the splits of a tile are neighbours in the grid)
+    bid /= nsplit;
     const int per_class = p.mtiles * p.ntiles_n;
     const int cls = bid / per_class;
     const int rem = bid - cls * per_class;
@@ -227,7 +236,11 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     const long long x2delta = reinterpret_cast<const char*>(p.x2) - x1c;
     const long long zdelta = reinterpret_cast<const char*>(g_ctsi_zero_page) - x1c;
     const int C1 = p.C1, C2 = p.C2, Cin = p.Cin, T = p.T, lcpt = p.lcpt;
-    int st_tap = 0, st_cc = 0;  // staging cursor (big mode): tap fastest, then 64-channel chunk
+    // K range of this block (split-K: big mode only; the host never splits SMALL plans)
+    const int s_per = (p.ksteps + nsplit - 1) / nsplit;
+    const int s_begin = split * s_per;
+    const int s_end = (s_begin + s_per < p.ksteps) ? s_begin + s_per : p.ksteps;
+    int st_tap = SMALL ? 0 : s_begin % p.T, st_cc = SMALL ? 0 : s_begin / p.T;  // staging cursor (big mode): tap fastest, then 64-channel chunk
     // small mode looks tap deltas up per lane: keep the table spread over the wave's lanes and
     // fetch with a lane permute (no LDS memory access, so it never orders against the DMA).
     const int td_tab = (lane < T) ? p.tapdelta[tapbase + lane] : 0;
@@ -367,7 +380,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) koff[kk] = (((kk * 2 + (lane >> 5)) ^ fsw) << 4) + frow;
 
-    const int S = p.ksteps;
+    const int S = s_end - s_begin;                       // K-steps this block walks: absolute steps s_begin + i
     auto compute = [&](const char* cur) {
         const char* a_base = cur + (wm * TM * 32) * 128;
         const char* b_base = cur + A_BYTES + (wn * TN * 32) * 128;
@@ -392,7 +405,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         // requires step s to have landed ((NSTG-2) * DPS younger DMA instructions of this wave may stay in flight)
 #pragma unroll
         for (int i = 0; i < NSTG - 1; ++i)
-            if (i < S) stage(i, smem + i * STAGE);
+            if (i < S) stage(s_begin + i, smem + i * STAGE);
         int slot = 0;
         for (int s = 0; s < S; ++s) {
             if (s + NSTG - 2 < S)
@@ -400,23 +413,70 @@ conv_gather_mfma_kernel(const ConvKParams p) {
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (s + NSTG - 1 < S) stage(s + NSTG - 1, smem + (slot == 0 ? NSTG - 1 : slot - 1) * STAGE);
+            if (s + NSTG - 1 < S) stage(s_begin + s + NSTG - 1, smem + (slot == 0 ? NSTG - 1 : slot - 1) * STAGE);
             compute(smem + slot * STAGE);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             slot = (slot + 1 == NSTG) ? 0 : slot + 1;
         }
     } else {
-        if (!(p.dbg & 4)) stage(0, smem);
+        if (!(p.dbg & 4) && S > 0) stage(s_begin, smem);
         for (int s = 0; s < S; ++s) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             char* cur = smem + (s & 1) * STAGE;
-            if (s + 1 < S) stage(s + 1, smem + ((s + 1) & 1) * STAGE);
+            if (s + 1 < S) stage(s_begin + s + 1, smem + ((s + 1) & 1) * STAGE);
             compute(cur);
         }
     }
     __syncthreads();  // every wave is done with the stage buffers
     if (p.dbg & 2) return;
+    if constexpr (TM == 2 && TN == 2)          // (the host splits 128 x 128-tile plans only: keep the other forms' code lean)
+    if (nsplit > 1) {
+        // Split-K hand-off, S-way (conv3_halo_k32.hip has the 2-way form): every block parks its accumulators with agent-scope
+        // (sc1) stores, drains them, and only then takes a ticket; the block that draws the LAST ticket therefore finds all
+        // parked tiles complete -- no spinning -- and sums them IN SPLIT ORDER (its own included, read back like the others):
+        // the result does not depend on which block came last.  No cache maintenance: every access to the parked bytes is sc1.
+        constexpr int NREG = TM * TN * 16;
+        const int tile = bid;                                 // (class, m-tile, n-tile) index
+        float* wst = p.sk_ws + ((size_t)tile * nsplit) * NREG * NTH + tid;
+        float* mine = wst + (size_t)split * NREG * NTH;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(mine + (size_t)((i * TN + j) * 16 + r) * NTH, acc[i][j][r], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* s_tk = reinterpret_cast<int*>(smem);
+        if (tid == 0) *s_tk = __hip_atomic_fetch_add(p.sk_sync + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = *s_tk;
+        __syncthreads();
+        if (ticket != nsplit - 1) return;
+        if (tid == 0) __hip_atomic_store(p.sk_sync + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        // (split loop OUTSIDE the register loops: the NREG loads of one parked tile are independent and go out back to back;
+        //  with the loops the other way round every register waited for its own S dependent round trips: 123 us per launch)
+        for (int k = 0; k < nsplit; ++k) {
+            float tmp[TM][TN][16];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tmp[i][j][r] = __hip_atomic_load(wst + ((size_t)k * NREG + (i * TN + j) * 16 + r) * NTH, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = k == 0 ? tmp[i][j][r] : acc[i][j][r] + tmp[i][j][r];
+        }
+    }
 
     // ---- epilogue --------------------------------------------------------------------------------
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);                          // [BM][BN]
@@ -648,6 +708,7 @@ struct ctsi_conv_plan {
     int fast, dshift;
     int h32_w16;    // halo3 == 2 only: 1 = 4x4x16 tile (two W-lines of 16 per A tile), 2 = 3x4x16 tile, instead of 4x2x32
     int m512_w16;   // halo3 == 7 only: tile of the k32 kernel: 0 = 4x4x32, 2 = 4x8x16, 3 = 3x4x32, 5 = 3x8x16 (384 voxels)
+    int gsplit;     // gather kernel (halo3 == 0): S-way split-K for launches of a few dozen blocks with a deep K loop (needs a workspace)
     int ds;         // halo3 == 7: the strided (3,4,4)/(1,2,2) Downsample form of the k32 kernel (conv3_halo_k32.hip, DS)
     int ksplit;     // halo3 == 7, tile 5: 2 = two blocks per (tile, n-tile), each half of the input-channel chunks (needs a workspace)
     int halo3;  // 3x3x3 halo-tile kernels: 2 = conv3_halo32_kernel (conv3_halo.hip: 4x2x32 / 4x4x16 / 3x4x16 tiles), 6 = few-cout
@@ -1090,6 +1151,22 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
         const double extent = ((double)(p->TD + 4) * d.hi * d.wi + 2.0 * d.wi + 8) * cmax * 2.0 * (p->sH > 1 ? 1 : 1);
         p->fast = !p->small && d.c1 % 64 == 0 && d.c2 % 64 == 0 && extent < 2.0e9 && !getenv("CTSI_CONV_NO_FAST");
     }
+    p->gsplit = 0;
+    if (!p->halo3 && !p->small && p->BM == 128 && p->BN == 128) {
+        // S-way split-K on the gather kernel: a layer that is a few dozen blocks (the 6 x 6 level of ONE 192^2 patch: 14 m-tiles
+        // x 4 n-tiles = 56 blocks on 256 CUs) with hundreds of sequential K-steps is bound by its K-step latency; S blocks
+        // per tile walk 1 / S of the steps each (csrc/conv_mfma.hip, hand-off by ticket).  CTSI_CONV_GSPLIT = 0 | 2..8 overrides.
+        const long long blocks = (long long)p->nclass * p->mtiles * p->ntiles_n;
+        int S = 0;
+        if (blocks * 2 <= 256 && p->ksteps >= 32) {
+            S = (int)(256 / blocks);
+            if (S > 4) S = 4;
+            while (S > 1 && p->ksteps / S < 16) --S;
+        }
+        const char* gs = getenv("CTSI_CONV_GSPLIT");
+        if (gs) S = atoi(gs) >= 2 && atoi(gs) <= 8 && p->ksteps >= atoi(gs) ? atoi(gs) : 0;
+        p->gsplit = S >= 2 ? S : 0;
+    }
     if (!d.transposed)
         p->flops = 2.0 * d.n * (double)p->Do * p->Ho * p->Wo * p->Cin * d.cout * KK;
     else
@@ -1121,6 +1198,10 @@ extern "C" int ctsi_conv_plan_cout_pad(const ctsi_conv_plan* p) { return p ? p->
 extern "C" double ctsi_conv_plan_flops(const ctsi_conv_plan* p) { return p ? p->flops : 0.0; }
 extern "C" size_t ctsi_conv_plan_workspace_bytes(const ctsi_conv_plan* p) {
     // split-K plans: tickets / flags + fp32 partial accumulators (ctsi_conv_out.workspace; zero the first 8 * tiles bytes once)
+    if (p && !p->halo3 && p->gsplit >= 2) {   // gather kernel: [tile] tickets (padded to 256 B) + [tile][split][128 x 128] fp32
+        const size_t tiles = (size_t)p->nclass * p->mtiles * p->ntiles_n;
+        return (tiles * 4 + 255) / 256 * 256 + tiles * p->gsplit * (size_t)(128 * 128) * sizeof(float);
+    }
     if (!p || p->ksplit != 2) return 0;
     return ctsi_conv3_halo_k32_splitk_bytes(p->mtiles * p->ntiles_n);
 }
@@ -1305,7 +1386,14 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
     memcpy(k.bh, p->bh, sizeof(k.bh));
     memcpy(k.cw, p->cw, sizeof(k.cw));
     for (int c = 0; c < 4; ++c) { k.pH[c] = p->pH[c]; k.pW[c] = p->pW[c]; }
-    const int grid = p->nclass * p->mtiles * p->ntiles_n;
+    int grid = p->nclass * p->mtiles * p->ntiles_n;
+    if (p->gsplit >= 2 && o->workspace != nullptr && !(p->BM != 128 || p->BN != 128)) {
+        const size_t tiles = (size_t)grid;
+        k.ksplit = p->gsplit;
+        k.sk_sync = (int*)o->workspace;
+        k.sk_ws = (float*)((char*)o->workspace + (tiles * 4 + 255) / 256 * 256);
+        grid *= p->gsplit;
+    }
     hipStream_t st = (hipStream_t)stream;
     {   // timing-only ablation knob (wrong results): truncate the K loop to price prologue + epilogue
         static const char* dbg = getenv("CTSI_DEBUG_KSTEPS");

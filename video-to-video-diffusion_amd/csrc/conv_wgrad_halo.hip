@@ -6,22 +6,30 @@
 // conv_wgrad_kernel / conv_wgrad_s1_kernel (conv_wgrad.hip) run ONE tap (or the 3 kw taps) of a 128 x 128 channel tile per
 // block: every K-step re-stages an R slab and a shifted G slab (64 / 190 flop per byte of LDS fill) and every wave re-reads
 // both operands from LDS for 16 (32) accumulator tiles: 36-38 % MFMA busy, 0.26-0.29 of peak (profiles/r03_pmc_mfma_busy_train.json).
-// Here a block owns ONE 16-input-channel chunk x 128 output channels x ALL 27 taps and walks voxel tiles (3x8x8 / 6x4x8 /
-// 3x4x16 = 192 voxels).  Per tile it stages
+// Here a block owns ONE 16-input-channel chunk x 128 output channels x ALL 27 taps and walks 192-voxel tiles (3x8x8, 6x4x8,
+// 3x4x16, 4x4x12 for 12- / 24-wide planes, 8x6x4 for 6-wide ones: the host picks the one with the largest useful fraction).
+// Per tile it stages
 //   * the X halo tile of its chunk, (TD+2)(TH+2)(TW+2) voxels x 32 B -- the 27 taps read it at shifted LDS addresses, exactly
 //     like the forward kernel's A operand (out-of-volume rows are zero-filled by the DMA: no validity masks), and
 //   * the dY tile, 192 voxels x 128 couts, as eight [16-cout chunk][voxel][32 B] slabs,
-// 67 KB for 27 x 16 x 128 x 192 x 2 = 21.2 MFLOP: 317 flop per byte of LDS fill (the forward kernel: 385).  Both operands are
+// 67-78 KB for 27 x 16 x 128 x 192 x 2 = 21.2 MFLOP: 317 flop per byte of LDS fill (the forward kernel: 385).  Both operands are
 // k-major ([voxel][channel]) and are read with gfx950's transposing LDS read ds_read_b64_tr_b16 straight into
 // v_mfma_f32_16x16x32_bf16 operands: M = 16 input channels of one tap, N = 16 output channels, K = 32 voxels.  The 8 waves
 // are 4 tap groups x 2 cout halves: a wave holds 7 taps x 4 cout tiles = 28 accumulator tiles (112 registers) and reads
 // 7 + 4 fragments per 28 MFMAs (0.39 per MFMA; the forward kernel: 0.375).
+// K <-> voxel mapping: the tile's voxels (w fastest) form 48 blocks of 4 voxels along w; K-step s owns blocks 8 s .. 8 s + 7 and
+// k-group kg / half e reads block 8 s + 4 e + kg -- table-driven per lane (a_step[s][e]), so TW only has to be a multiple of 4
+// and blocks may straddle W-lines and depth slices.
 // LDS layout for conflict-free transposed reads (a 16-lane group reads 4 voxel rows x 32 B = 128 contiguous bytes; the two
-// groups served together must fall into different 128-byte halves of the 256-byte bank period): the halo tile's w-stride is
-// padded to HWP rows with HWP * 32 = 128 (mod 256), and the voxels of a K-step are stored in the order (e, kg, q) so that
-// k-groups kg and kg + 1 are 128 B apart (the DMA's per-lane source address does the permutation).
+// groups served together -- k-groups kg, kg + 1 = CONSECUTIVE voxel blocks -- must fall into different 128-byte halves of the
+// 256-byte bank period): the halo tile's w-stride is padded to HWP rows, a multiple of 4 with an odd quarter (same line: + 4
+// rows; next line: + HWP - 4 (TW - 4) rows; next slice: both = 128 B modulo 256), and the dY voxels of a K-step are stored in
+// the order (e, kg, q) (the DMA's per-lane source address does the permutation).
+// Main loop: the A fragment of unit u + 2 and the next step's B fragments load under unit u's MFMAs; the next tile's DMA pieces
+// are issued one per 4 units, SIMD partners two units apart.  1055-1150 TFLOP/s on the large layers (the one-tap kernel: 700-850),
+// MFMA busy 57-58 % (36 %): profiles/r03_notes.md.
 // Split-K over voxel-tile ranges: partial [slice][tap][cout][cin] fp32 tiles in the workspace, summed in a fixed order by
-// conv_wgrad_reduce_kernel (deterministic), as for the other weight-gradient kernels.
+// conv_wgrad_reduce_t_kernel (deterministic), as for the other weight-gradient kernels.
 #include "conv3_halo_common.h"
 #include <stdlib.h>
 

@@ -1162,7 +1162,9 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             S = (int)(256 / blocks);
             if (S > 4) S = 4;
             while (S > 1 && p->ksteps / S < 16) --S;
-        }
+        } else if (blocks <= 256 && p->ksteps >= 64) {
+            S = 2;     // 129-256 blocks: the grid doubles past the ring mode's one-block-per-CU limit, so the two half-K blocks of
+        }              // a tile share a CU in the 2-stage mode: 560 -> 700 TFLOP/s on the 6 x 6 level of config 3 (B = 4)
         const char* gs = getenv("CTSI_CONV_GSPLIT");
         if (gs) S = atoi(gs) >= 2 && atoi(gs) <= 8 && p->ksteps >= atoi(gs) ? atoi(gs) : 0;
         p->gsplit = S >= 2 ? S : 0;

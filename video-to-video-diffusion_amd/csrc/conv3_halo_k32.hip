@@ -124,7 +124,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     int bid = xcd_remap_h(blockIdx.x, gridDim.x);
-    const int khalf = SK ? (bid & 1) : 0;                    // the two halves of a tile are neighbours in the grid
+    const int khalf = SK ? (bid & 1) : 0;                   // the two halves of a tile are neighbours in the grid
     if (SK) bid >>= 1;
     int mt, nt, cls = 0;
     if (TR) {

@@ -73,6 +73,23 @@ __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// the same on a channel pair (one bf16x2 dword): elementwise identical to silu_f / pack_bf16x2
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t silu2_f(f32x2_t x) {
+    f32x2_t t = x * -1.4426950408889634f;
+    t.x = __builtin_amdgcn_exp2f(t.x);
+    t.y = __builtin_amdgcn_exp2f(t.y);
+    t = 1.0f + t;
+    t.x = __builtin_amdgcn_rcpf(t.x);
+    t.y = __builtin_amdgcn_rcpf(t.y);
+    return x * t;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2_v(f32x2_t v) {
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return *reinterpret_cast<const uint32_t*>(&b);
+}
+
 __device__ __forceinline__ float nan_to_num_f(float v) {
     // torch.nan_to_num(v, nan=0.0, posinf=1.0, neginf=-1.0)
     if (v != v) return 0.0f;

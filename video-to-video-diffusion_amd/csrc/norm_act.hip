@@ -199,13 +199,16 @@ extern "C" int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c,
 }
 
 // ---- apply --------------------------------------------------------------------------------------
-// grid: (blocks_per_sample, n); block 256.  scale/shift for the sample's channels live in LDS.
+// grid: (blocks_per_sample, n); block 256.  The four options are template parameters: with run-time flags the compiler
+// if-converted both SiLU sites into unconditional code (2 exp + 2 rcp per element and a select chain: ~25 VALU instructions
+// per element, 2.3 TB/s each way -- VALU-bound, not HBM-bound).  CONSTQ: the grid stride is a multiple of the row's chunk
+// count, so a thread meets the same 8 channels every iteration and keeps their scale / shift / time bias in registers.
+template <bool SILU_PRE, bool TB, bool RES, bool SILU_POST, bool CONSTQ>
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const double* __restrict__ sums,
                 const float* __restrict__ gamma, const float* __restrict__ beta, int c, long long vox,
-                long long vox_stat, int groups, float eps, int silu_pre, const float* __restrict__ tbias, int tbias_stride,
-                const int* __restrict__ step_ptr, int n_total, const bf16_t* __restrict__ residual,
-                int silu_post) {
+                long long vox_stat, int groups, float eps, const float* __restrict__ tbias, int tbias_stride,
+                const int* __restrict__ step_ptr, int n_total, const bf16_t* __restrict__ residual) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* s_scale = reinterpret_cast<float*>(smem_raw);
     float* s_shift = s_scale + c;
@@ -214,7 +217,7 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const doub
     const int cpg = c / groups;
     const double cnt = (double)cpg * (double)vox_stat;
     long long trow = nb;
-    if (step_ptr) trow += (long long)(*step_ptr) * n_total;
+    if (TB && step_ptr) trow += (long long)(*step_ptr) * n_total;
     for (int ch = tid; ch < c; ch += 256) {
         const int g = ch / cpg;
         const double m = sums[((long long)nb * groups + g) * 2 + 0] / cnt;
@@ -224,41 +227,52 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const doub
         const float sc = gamma[ch] * rstd;
         s_scale[ch] = sc;
         s_shift[ch] = beta[ch] - (float)m * sc;
-        s_tb[ch] = tbias ? tbias[trow * tbias_stride + ch] : 0.0f;
+        if (TB) s_tb[ch] = tbias[trow * tbias_stride + ch];
     }
     __syncthreads();
     const int cpr = c >> 3;
     const long long total = vox * cpr;
     const bf16_t* xb = x + (long long)nb * vox * c;
     bf16_t* yb = y + (long long)nb * vox * c;
-    const bf16_t* rb = residual ? residual + (long long)nb * vox * c : nullptr;
+    const bf16_t* rb = RES ? residual + (long long)nb * vox * c : nullptr;
     const long long stride = (long long)gridDim.x * 256;
-    const int dq = (int)(stride % cpr);
+    const int dq = CONSTQ ? 0 : (int)(stride % cpr);
     int q = (int)(((long long)blockIdx.x * 256 + tid) % cpr);   // 8-channel chunk index inside the voxel row
-    constexpr int U = 4;   // independent 16-byte loads in flight per thread (HBM latency, not issue, bounds this kernel)
+    constexpr int U = 4;   // independent 16-byte loads in flight per thread
     long long e = (long long)blockIdx.x * 256 + tid;
-    auto one = [&](const uint4 raw, const uint4 rraw, long long ee, int qq) {
-        float f[8], r[8];
-        unpack8(raw, f);
-        if (rb) unpack8(rraw, r);
-        // per-channel scale / shift / time-bias as 16-byte LDS reads (6 per chunk instead of 24 scalar ones)
-        float sc[8], sh[8], tb[8];
+    float csc[8], csh[8], ctb[8];
+    auto coef = [&](int qq, float* sc, float* sh, float* tb) {   // 16-byte LDS reads
         *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(s_scale + qq * 8);
         *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(s_scale + qq * 8 + 4);
         *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(s_shift + qq * 8);
         *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(s_shift + qq * 8 + 4);
-        *reinterpret_cast<float4*>(tb) = *reinterpret_cast<const float4*>(s_tb + qq * 8);
-        *reinterpret_cast<float4*>(tb + 4) = *reinterpret_cast<const float4*>(s_tb + qq * 8 + 4);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float v = f[k] * sc[k] + sh[k];
-            if (silu_pre) v = silu_f(v);
-            v += tb[k];
-            if (rb) v += r[k];
-            if (silu_post) v = silu_f(v);
-            f[k] = v;
+        if (TB) {
+            *reinterpret_cast<float4*>(tb) = *reinterpret_cast<const float4*>(s_tb + qq * 8);
+            *reinterpret_cast<float4*>(tb + 4) = *reinterpret_cast<const float4*>(s_tb + qq * 8 + 4);
         }
-        *reinterpret_cast<uint4*>(yb + ee * 8) = pack8(f);
+    };
+    if (CONSTQ) coef(q, csc, csh, ctb);
+    // one dword = channels (2 j, 2 j + 1): the pair stays a 2-vector from the unpack to the single v_cvt_pk_bf16_f32
+    auto one = [&](const uint4 raw, const uint4 rraw, long long ee, int qq) {
+        float lsc[8], lsh[8], ltb[8];
+        if (!CONSTQ) coef(qq, lsc, lsh, ltb);
+        const float* sc = CONSTQ ? csc : lsc;
+        const float* sh = CONSTQ ? csh : lsh;
+        const float* tb = CONSTQ ? ctb : ltb;
+        const uint32_t xin[4] = {raw.x, raw.y, raw.z, raw.w}, rin[4] = {rraw.x, rraw.y, rraw.z, rraw.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x2_t v = {__uint_as_float(xin[j] << 16), __uint_as_float(xin[j] & 0xffff0000u)};
+            const f32x2_t s2 = {sc[2 * j], sc[2 * j + 1]}, h2 = {sh[2 * j], sh[2 * j + 1]};
+            v = v * s2 + h2;
+            if (SILU_PRE) v = silu2_f(v);
+            if (TB) v += f32x2_t{tb[2 * j], tb[2 * j + 1]};
+            if (RES) v += f32x2_t{__uint_as_float(rin[j] << 16), __uint_as_float(rin[j] & 0xffff0000u)};
+            if (SILU_POST) v = silu2_f(v);
+            o[j] = pack_bf16x2_v(v);
+        }
+        *reinterpret_cast<uint4*>(yb + ee * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     };
     for (; e + (U - 1) * stride < total; e += U * stride) {
         uint4 raw[U], rraw[U];
@@ -266,17 +280,30 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const doub
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             raw[u] = *reinterpret_cast<const uint4*>(xb + (e + u * stride) * 8);
-            rraw[u] = rb ? *reinterpret_cast<const uint4*>(rb + (e + u * stride) * 8) : make_uint4(0, 0, 0, 0);
+            rraw[u] = RES ? *reinterpret_cast<const uint4*>(rb + (e + u * stride) * 8) : make_uint4(0, 0, 0, 0);
             qs[u] = q;
-            q = (q + dq >= cpr) ? q + dq - cpr : q + dq;
+            if (!CONSTQ) q = (q + dq >= cpr) ? q + dq - cpr : q + dq;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) one(raw[u], rraw[u], e + u * stride, qs[u]);
     }
-    for (; e < total; e += stride, q = (q + dq >= cpr) ? q + dq - cpr : q + dq) {
+    for (; e < total; e += stride) {
         const uint4 raw = *reinterpret_cast<const uint4*>(xb + e * 8);
-        const uint4 rraw = rb ? *reinterpret_cast<const uint4*>(rb + e * 8) : make_uint4(0, 0, 0, 0);
+        const uint4 rraw = RES ? *reinterpret_cast<const uint4*>(rb + e * 8) : make_uint4(0, 0, 0, 0);
         one(raw, rraw, e, q);
+        if (!CONSTQ) q = (q + dq >= cpr) ? q + dq - cpr : q + dq;
+    }
+}
+
+typedef void (*gn_apply_fn)(const bf16_t*, bf16_t*, const double*, const float*, const float*, int, long long, long long, int,
+                            float, const float*, int, const int*, int, const bf16_t*);
+template <int I>
+static gn_apply_fn gn_apply_pick(int idx) {
+    if constexpr (I >= 32) {
+        return nullptr;
+    } else {
+        if (idx == I) return gn_apply_kernel<(I & 1) != 0, (I & 2) != 0, (I & 4) != 0, (I & 8) != 0, (I & 16) != 0>;
+        return gn_apply_pick<I + 1>(idx);
     }
 }
 
@@ -292,11 +319,18 @@ extern "C" int ctsi_gn_apply(const void* x, void* y, const double* sums, const f
     long long blocks = (total + 256 * 8 - 1) / (256 * 8);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
+    // a grid stride that is a multiple of the chunks per voxel row (c / 8) keeps every thread on one 8-channel chunk
+    const int cpr = c / 8;
+    int gq = cpr, g256 = 256;
+    while (g256) { const int t = gq % g256; gq = g256; g256 = t; }     // gq = gcd(cpr, 256)
+    const int need = cpr / gq;                                         // blocks must be a multiple of this
+    if (blocks >= need) blocks -= blocks % need;
+    const bool constq = (blocks * 256) % cpr == 0;
     const size_t lds = (size_t)c * 3 * sizeof(float);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, n), dim3(256), lds, (hipStream_t)stream,
+    const int idx = (silu_pre ? 1 : 0) | (tbias ? 2 : 0) | (residual ? 4 : 0) | (silu_post ? 8 : 0) | (constq ? 16 : 0);
+    hipLaunchKernelGGL(gn_apply_pick<0>(idx), dim3((unsigned)blocks, n), dim3(256), lds, (hipStream_t)stream,
                        (const bf16_t*)x, (bf16_t*)y, sums, gamma, beta, c, vox, (long long)d_stat * h * w, groups, eps,
-                       silu_pre, tbias,
-                       tbias_stride, step_ptr, n, (const bf16_t*)residual, silu_post);
+                       tbias, tbias_stride, step_ptr, n, (const bf16_t*)residual);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

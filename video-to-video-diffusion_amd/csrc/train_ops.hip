@@ -36,11 +36,14 @@ __device__ __forceinline__ float silu_grad_f(float z) {
 //           dgamma = sum g*xhat, dbeta = sum g.
 // Pass 1 (this kernel): writes g (bf16) and per-tile column sums [n][tiles][4][c] = (sum g, sum g*xhat, sum gc, sum xhat).
 // grid (tiles, n), block 256.  dy may be a depth-broadcast tensor (n, 1, h, w, c): dy_mod = h*w, else 0.
+// SILU_PRE / RES / SILU_POST are template parameters: as run-time flags the compiler evaluated both SiLU sites for every
+// element and selected afterwards (the kernel was VALU-bound, like gn_apply before its options became template parameters).
+template <bool SILU_PRE, bool RES, bool SILU_POST>
 __global__ void __launch_bounds__(256)
 gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, long long dy_mod,
                      const double* __restrict__ sums, const float* __restrict__ gamma,
-                     const float* __restrict__ beta, int c, long long vox, int groups, float eps, int silu_pre,
-                     const bf16_t* __restrict__ residual, int silu_post, bf16_t* __restrict__ g_out,
+                     const float* __restrict__ beta, int c, long long vox, int groups, float eps,
+                     const bf16_t* __restrict__ residual, bf16_t* __restrict__ g_out,
                      float* __restrict__ colsum3, int tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* s_rs = reinterpret_cast<float*>(smem_raw);   // rstd
@@ -74,7 +77,7 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
     for (int k = 0; k < 8; ++k) a0[k] = a1[k] = a2[k] = a3[k] = 0.0f;
     if (rl < rows_par) {
         const bf16_t* xb = x + (long long)nb * vox * c + q * 8;
-        const bf16_t* rb = residual ? residual + (long long)nb * vox * c + q * 8 : nullptr;
+        const bf16_t* rb = (RES && SILU_POST) ? residual + (long long)nb * vox * c + q * 8 : nullptr;
         bf16_t* gb = g_out + (long long)nb * vox * c + q * 8;
         const bf16_t* db = dy + (long long)nb * (dy_mod ? dy_mod : vox) * c + q * 8;
         float rs[8], mr[8], ga[8], be[8];
@@ -93,7 +96,7 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
                     xr[u] = *reinterpret_cast<const uint4*>(xb + v * c);
                     const long long dv = dy_mod ? (v % dy_mod) : v;
                     dr[u] = *reinterpret_cast<const uint4*>(db + dv * c);
-                    if (rb) rr[u] = *reinterpret_cast<const uint4*>(rb + v * c);
+                    if (RES && SILU_POST) rr[u] = *reinterpret_cast<const uint4*>(rb + v * c);
                 }
             }
 #pragma unroll
@@ -103,19 +106,19 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
                 float xf[8], df[8], rf[8], gf[8];
                 t_unpack8(xr[u], xf);
                 t_unpack8(dr[u], df);
-                if (rb) t_unpack8(rr[u], rf);
+                if (RES && SILU_POST) t_unpack8(rr[u], rf);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float xh = xf[k] * rs[k] + mr[k];
                     const float h = xh * ga[k] + be[k];
                     float gc = df[k];
-                    if (silu_post) {
-                        float cc = silu_pre ? silu_f(h) : h;
-                        if (rb) cc += rf[k];
+                    if (SILU_POST) {
+                        float cc = SILU_PRE ? silu_f(h) : h;
+                        if (RES) cc += rf[k];
                         gc *= silu_grad_f(cc);
                     }
                     float g = gc;
-                    if (silu_pre) g *= silu_grad_f(h);
+                    if (SILU_PRE) g *= silu_grad_f(h);
                     gf[k] = g;
                     a0[k] += g;
                     a1[k] += g * xh;
@@ -237,7 +240,9 @@ gn_bwd_param_kernel(const float* __restrict__ pgrad, int n, int c, float* __rest
     if (dxsum) dxsum[ch] = d;
 }
 
-// Pass 3: dx = rstd*(gamma*g - S1/m - xhat*S2/m) (+ add).  grid (blocks, n), block 256.
+// Pass 3: dx = rstd*(gamma*g - S1/m - xhat*S2/m) (+ add).  grid (blocks, n), block 256.  The grid stride is a multiple of the
+// row's chunk count (the host picks the block count so), so a thread keeps its 8 channels' five coefficients in registers.
+template <bool ADD>
 __global__ void __launch_bounds__(256)
 gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, const double* __restrict__ sums,
                     const float* __restrict__ gamma, const float* __restrict__ s12,
@@ -269,25 +274,50 @@ gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, 
     const long long total = vox * cpr;
     const bf16_t* gb = g + (long long)nb * vox * c;
     const bf16_t* xb = x + (long long)nb * vox * c;
-    const bf16_t* ab = add ? add + (long long)nb * vox * c : nullptr;
+    const bf16_t* ab = ADD ? add + (long long)nb * vox * c : nullptr;
     bf16_t* ob = dx + (long long)nb * vox * c;
     const long long stride = (long long)gridDim.x * 256;
-    for (long long e = (long long)blockIdx.x * 256 + tid; e < total; e += stride) {
-        const int q = (int)(e % cpr);
+    const long long e0 = (long long)blockIdx.x * 256 + tid;
+    const int q = (int)(e0 % cpr);                       // stride % cpr == 0: the same chunk every iteration
+    float rs[8], mr[8], ag[8], b1[8], b2[8];
+#pragma unroll
+    for (int k = 0; k < 8; k += 4) {
+        *reinterpret_cast<float4*>(rs + k) = *reinterpret_cast<const float4*>(s_rs + q * 8 + k);
+        *reinterpret_cast<float4*>(mr + k) = *reinterpret_cast<const float4*>(s_mr + q * 8 + k);
+        *reinterpret_cast<float4*>(ag + k) = *reinterpret_cast<const float4*>(s_ag + q * 8 + k);
+        *reinterpret_cast<float4*>(b1 + k) = *reinterpret_cast<const float4*>(s_b1 + q * 8 + k);
+        *reinterpret_cast<float4*>(b2 + k) = *reinterpret_cast<const float4*>(s_b2 + q * 8 + k);
+    }
+    auto one = [&](const uint4 graw, const uint4 xraw, const uint4 araw, long long e) {
         float gf[8], xf[8], af[8], of[8];
-        t_unpack8(*reinterpret_cast<const uint4*>(gb + e * 8), gf);
-        t_unpack8(*reinterpret_cast<const uint4*>(xb + e * 8), xf);
-        if (ab) t_unpack8(*reinterpret_cast<const uint4*>(ab + e * 8), af);
+        t_unpack8(graw, gf);
+        t_unpack8(xraw, xf);
+        if (ADD) t_unpack8(araw, af);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int ch = q * 8 + k;
-            const float xh = xf[k] * s_rs[ch] + s_mr[ch];
-            float v = s_ag[ch] * gf[k] - s_b1[ch] - xh * s_b2[ch];
-            if (ab) v += af[k];
+            const float xh = xf[k] * rs[k] + mr[k];
+            float v = ag[k] * gf[k] - b1[k] - xh * b2[k];
+            if (ADD) v += af[k];
             of[k] = v;
         }
         *reinterpret_cast<uint4*>(ob + e * 8) = t_pack8(of);
+    };
+    constexpr int U = 2;                                 // independent iterations in flight (4-6 16-byte loads)
+    long long e = e0;
+    for (; e + (U - 1) * stride < total; e += U * stride) {
+        uint4 gr[U], xr[U], ar[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            gr[u] = *reinterpret_cast<const uint4*>(gb + (e + u * stride) * 8);
+            xr[u] = *reinterpret_cast<const uint4*>(xb + (e + u * stride) * 8);
+            ar[u] = ADD ? *reinterpret_cast<const uint4*>(ab + (e + u * stride) * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(gr[u], xr[u], ar[u], e + u * stride);
     }
+    for (; e < total; e += stride)
+        one(*reinterpret_cast<const uint4*>(gb + e * 8), *reinterpret_cast<const uint4*>(xb + e * 8),
+            ADD ? *reinterpret_cast<const uint4*>(ab + e * 8) : make_uint4(0, 0, 0, 0), e);
 }
 
 extern "C" int ctsi_gn_bwd_tiles(int d, int h, int w) {
@@ -316,12 +346,20 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
     CTSI_CHECK_ARG(rows_par >= 1, "ctsi_gn_bwd: c=%d too wide", c);
     const size_t lds1 = (size_t)(4 * c + rows_par * 4 * c) * sizeof(float);
     CTSI_CHECK_ARG(lds1 <= 160 * 1024, "ctsi_gn_bwd: LDS budget exceeded for c=%d", c);
+    typedef void (*reduce_fn)(const bf16_t*, const bf16_t*, long long, const double*, const float*, const float*, int, long long,
+                              int, float, const bf16_t*, bf16_t*, float*, int);
+    static const reduce_fn reduce_tab[8] = {
+        gn_bwd_reduce_kernel<false, false, false>, gn_bwd_reduce_kernel<true, false, false>,
+        gn_bwd_reduce_kernel<false, true, false>,  gn_bwd_reduce_kernel<true, true, false>,
+        gn_bwd_reduce_kernel<false, false, true>,  gn_bwd_reduce_kernel<true, false, true>,
+        gn_bwd_reduce_kernel<false, true, true>,   gn_bwd_reduce_kernel<true, true, true>};
+    const reduce_fn reduce = reduce_tab[(silu_pre ? 1 : 0) | (residual ? 2 : 0) | (silu_post ? 4 : 0)];
     if (lds1 > 64 * 1024)
-        CTSI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_bwd_reduce_kernel),
+        CTSI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(reduce),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(tiles, n), dim3(256), lds1, st, (const bf16_t*)x, (const bf16_t*)dy,
-                       dy_bcast_d ? (long long)h * w : 0ll, sums, gamma, beta, c, vox, groups, eps, silu_pre,
-                       (const bf16_t*)residual, silu_post, (bf16_t*)g_buf, colsum3, tiles);
+    hipLaunchKernelGGL(reduce, dim3(tiles, n), dim3(256), lds1, st, (const bf16_t*)x, (const bf16_t*)dy,
+                       dy_bcast_d ? (long long)h * w : 0ll, sums, gamma, beta, c, vox, groups, eps,
+                       (const bf16_t*)residual, (bf16_t*)g_buf, colsum3, tiles);
     CTSI_LAUNCH_CHECK();
     {
         const int cpg = c / groups;
@@ -341,9 +379,20 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
     const long long total = vox * cpr;
     long long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)blocks, n), dim3(256), 5 * c * sizeof(float), st,
-                       (const bf16_t*)g_buf, (const bf16_t*)x, sums, gamma, s12, (const bf16_t*)add, (bf16_t*)dx, c, vox,
-                       groups, eps);
+    {   // grid stride = a multiple of the chunks per voxel row (cpr <= 256: one block's 256 threads times need)
+        int gq = cpr, g256 = 256;
+        while (g256) { const int t = gq % g256; gq = g256; g256 = t; }     // gcd(cpr, 256)
+        const int need = cpr / gq;
+        blocks = (blocks + need - 1) / need * need;
+    }
+    if (add)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)blocks, n), dim3(256), 5 * c * sizeof(float), st,
+                           (const bf16_t*)g_buf, (const bf16_t*)x, sums, gamma, s12, (const bf16_t*)add, (bf16_t*)dx, c, vox,
+                           groups, eps);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3((unsigned)blocks, n), dim3(256), 5 * c * sizeof(float), st,
+                           (const bf16_t*)g_buf, (const bf16_t*)x, sums, gamma, s12, (const bf16_t*)add, (bf16_t*)dx, c, vox,
+                           groups, eps);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

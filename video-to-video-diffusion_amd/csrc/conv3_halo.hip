@@ -8,6 +8,7 @@
 // let all 27 taps read their A operand from it at shifted LDS addresses; only the weights stream per tap.
 // (The round-1 16x16x32 form of the 4 x 4 x 16 tile lives under experiments/conv3_halo_w16.hip.)
 #include "conv3_halo_common.h"
+#include <type_traits>
 #include <string.h>
 
 // =====================================================================================================
@@ -150,13 +151,16 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
     const int rowb = wn * (TN * 32) + r;
     const int b_off = rowb * 64 + ((hk ^ ((rowb >> 2) & 3)) << 4);   // k-step 0; k-step 1 = ^32; n-tile 1 = +2048
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN];                                      // start value = the bias of the lane's cout (no bias pass later)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = bv;
+    }
 
     bf16x8 fa0[TM][2], fb0[TN][2], fa1[TM][2], fb1[TN][2], fa2[TM][2], fb2[TN][2];   // [tile][k-step]
     const int S = nchunks * 9;
@@ -296,34 +300,54 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
         }
         vbits[i] = vb;
     }
+    // per accumulator: half a v_cvt_pk_bf16_f32 (rows q, q + 1 share it), one 2-byte LDS write, one add + one fma for the column
+    // sums; the validity select only in waves that own rows outside the volume
+    auto tile_out = [&](auto masked_tag, auto sums_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value, SUMS = decltype(sums_tag)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = (wn * TN + j) * 32 + lcol;
-        const int co = n0 + col;
-        const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
-        float s1 = 0.0f, s2 = 0.0f;
+        for (int j = 0; j < TN; ++j) {
+            const int col = (wn * TN + j) * 32 + lcol;
+            float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            bf16_t* trow = s_tile + ((wm * TM + i) * 32 + 4 * lhi) * BN + col;
+            for (int i = 0; i < TM; ++i) {
+                bf16_t* trow = s_tile + ((wm * TM + i) * 32 + 4 * lhi) * BN + col;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float v = acc[i][j][q] + bv;
-                trow[((q & 3) + 8 * (q >> 2)) * BN] = f32_to_bf16(v);
-                if (want_sums) {
-                    const float vm = ((vbits[i] >> q) & 1u) ? v : 0.0f;
-                    s1 += vm;
-                    s2 += vm * vm;
+                for (int q = 0; q < 16; q += 2) {
+                    const float v0 = acc[i][j][q], v1 = acc[i][j][q + 1];
+                    const uint32_t pk = pack_bf16x2_v(f32x2_t{v0, v1});
+                    const int rr = (q & 3) + 8 * (q >> 2);
+                    trow[rr * BN] = (bf16_t)(pk & 0xffffu);
+                    trow[(rr + 1) * BN] = (bf16_t)(pk >> 16);
+                    if (SUMS) {
+                        const float m0 = (!MASKED || ((vbits[i] >> q) & 1u)) ? v0 : 0.0f;
+                        const float m1 = (!MASKED || ((vbits[i] >> (q + 1)) & 1u)) ? v1 : 0.0f;
+                        s1 += m0;
+                        s2 = __builtin_fmaf(m0, m0, s2);
+                        s1 += m1;
+                        s2 = __builtin_fmaf(m1, m1, s2);
+                    }
+                }
+            }
+            if (SUMS) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (lhi == 0) {
+                    s_cs[(wm * BN + col) * 2 + 0] = s1;
+                    s_cs[(wm * BN + col) * 2 + 1] = s2;
                 }
             }
         }
-        if (want_sums) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (lhi == 0) {
-                s_cs[(wm * BN + col) * 2 + 0] = s1;
-                s_cs[(wm * BN + col) * 2 + 1] = s2;
-            }
-        }
+    };
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        bool rg = false;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rg = rg || vbits[i] != 0xffffu;
+        const bool ragged = __builtin_amdgcn_ballot_w64(rg) != 0ull;   // wave-uniform
+        if (!want_sums) tile_out(F{}, F{});
+        else if (ragged) tile_out(T{}, T{});
+        else tile_out(F{}, T{});
     }
     __syncthreads();
     if (want_sums && tid < BN) {

@@ -21,6 +21,7 @@
 //     out by the DMA.
 #include "conv3_halo_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // <TD, TH, TW, BN, UPS>: tile TD x TH x TW = 512 or 384 voxels, BN couts per block, UPS units per step (one barrier per step):
 //   <4,4,32,128,2> / <4,8,16,128,2>: per wave 64 voxels x 128 couts (32 MFMAs, 12 ds_read_b128 per unit), steps of 4 entries;
@@ -52,7 +53,11 @@ struct HkCfg {
     static constexpr int NPIECE = (HALO_INSTR + NWAVE - 1) / NWAVE;   // halo DMAs per wave and chunk
     static constexpr int OFF_W = 2 * HALO_BYTES;
     static constexpr int LOOP_END = OFF_W + NWS * WSLOT_BYTES;
-    static constexpr int OFF_ROW = LOOP_END > BM * BN * 2 ? LOOP_END : BM * BN * 2;
+    // output tile rows padded by 16 B: rows 4 apart (the k-groups of one ds_write_b16) fall 16 banks apart instead of on the
+    // same banks (the unpadded 256-B rows cost every staging write a 2-way conflict: the LDS array, 4 cycles per write x 1024
+    // writes per tile, bounded the staging)
+    static constexpr int BNP = BN + 8;
+    static constexpr int OFF_ROW = LOOP_END > BM * BNP * 2 ? LOOP_END : BM * BNP * 2;
     static constexpr int OFF_CS = OFF_ROW + BM * 8;
     static constexpr int LDS_BYTES = OFF_CS + NWAVE * BN * 8;
     static constexpr int LPW = 64 / TW;                     // W-lines per wave
@@ -101,6 +106,11 @@ __device__ __forceinline__ void hk_wait_vm(int allowed) {   // wave-uniform `all
 // Sticky device-side error word ([0] = count, [1] = last tile): set when a split-K consumer's bounded wait expires (see the
 // hand-off below); read and cleared by ctsi_device_error_status().
 __device__ unsigned int g_hk_device_error[2] = {0u, 0u};
+// timing-only instrumentation (CTSI_DEBUG_FLAGS & 4096): per block, wave 0 records s_memtime at 7 points + its HW_ID
+#define HK_NSTAMP 4096
+__device__ unsigned long long g_hk_stamps[HK_NSTAMP][8];
+#define HK_STAMP(K)                                                                                              \
+    if ((p.dbg & 4096) && tid == 0 && blockIdx.x < HK_NSTAMP) g_hk_stamps[blockIdx.x][K] = __builtin_amdgcn_s_memtime();
 
 template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false, bool SK = false, bool DS = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, 512)))
@@ -115,6 +125,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     constexpr int HALO_INSTR = Cfg::HALO_INSTR, HALO_BYTES = Cfg::HALO_BYTES, BM = Cfg::BM, BN = Cfg::BN;
     constexpr int TAP_BYTES = Cfg::TAP_BYTES, WSLOT_BYTES = Cfg::WSLOT_BYTES, NWS = Cfg::NWS, NWAVE = Cfg::NWAVE;
     constexpr int NTH = Cfg::NTH, NPIECE = Cfg::NPIECE, OFF_W = Cfg::OFF_W, OFF_ROW = Cfg::OFF_ROW, OFF_CS = Cfg::OFF_CS;
+    constexpr int BNP = Cfg::BNP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long* s_rowoff = reinterpret_cast<long long*>(smem + OFF_ROW);
     float* s_cs = reinterpret_cast<float*>(smem + OFF_CS);
@@ -123,6 +134,10 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    HK_STAMP(0);
+    if ((p.dbg & 4096) && tid == 0 && blockIdx.x < HK_NSTAMP)
+        g_hk_stamps[blockIdx.x][7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32) |
+                                     (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
     int bid = xcd_remap_h(blockIdx.x, gridDim.x);
     const int khalf = SK ? (bid & 1) : 0;                   // the two halves of a tile are neighbours in the grid
     if (SK) bid >>= 1;
@@ -154,19 +169,6 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const int tH = r0 / p.tilesW;
     const int tW = r0 - tH * p.tilesW;
     const int d0 = tD * Cfg::TD, h0 = tH * TH, w0 = tW * TW;
-
-    if (tid < BM) {   // row = line * TW + m, line = ld * TH + lh
-        const int mm = tid % TW, line = tid / TW;
-        const int d = d0 + line / TH, h = h0 + line % TH, w = w0 + mm;
-        long long off = -1;
-        if (TR) {
-            if (d < p.Do && 2 * h < p.Ho && 2 * w < p.Wo)
-                off = ((((long long)nb * p.Do + d) * p.Ho + 2 * h + py) * p.Wo + 2 * w + px) * p.cout_stride + p.c_off;
-        } else if (d < p.Do && h < p.Ho && w < p.Wo) {
-            off = ((((long long)nb * p.Do + d) * p.Ho + h) * p.Wo + w) * p.cout_stride + p.c_off;
-        }
-        s_rowoff[tid] = off;
-    }
 
     int dlo = d0 + p.dshift - 1;
     dlo = dlo < 0 ? 0 : dlo;
@@ -288,12 +290,6 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     };
 
     f32x4 acc[MA][NJ];
-#pragma unroll
-    for (int i = 0; i < MA; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.0f;
 
     bf16x8 fa0[MA], fa1[MA], fbl[NJH], fbh[NJH];
 
@@ -325,14 +321,51 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
 
-    // prologue: halo of chunk 0, weights of steps 0..2
+    // prologue: the block's 128 bias values (one 512-byte LDS-DMA piece of wave 0 into the column-sum scratch; couts past Cout
+    // read as 0 through the buffer's range check), weights of step 0, halo of chunk 0 -- and BEHIND them the weights of steps
+    // 1 and 2, which may stay in flight when the loop starts: every CU runs its prologue at the same time and that burst is
+    // HBM-bound (13-14 k cycles per tile with all 87 KB awaited, tools/k32_stamps.py), so the loop starts on the first 55 KB.
+    const bool has_bias = p.bias != nullptr && khalf == 0;
+    if (has_bias && wave == 0) {
+        const int left = p.Cout - n0;
+        const v4i_t rsb = h3_make_rsrc(p.bias + n0, (unsigned)(left > 0 ? left * 4 : 0));
+        h3_dma16(rsb, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + OFF_CS)), (unsigned)lane * 16u, 0u);
+    }
+    if (S > 0) issue_weights(0);
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) issue_halo(0, i);
+    int n_trail = 0;                 // pieces of steps 1 and 2 (the youngest of this wave)
 #pragma unroll
-    for (int s = 0; s < NWS - 1; ++s)
-        if (s < S) issue_weights(s);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int s = 1; s < NWS - 1; ++s)
+        if (s < S) {
+            issue_weights(s);
+            n_trail += 2;
+        }
+    if (tid < BM) {   // output row offsets (read in the epilogue only): computed while the DMAs fly; row = line * TW + m, line = ld * TH + lh
+        const int mm = tid % TW, line = tid / TW;
+        const int d = d0 + line / TH, h = h0 + line % TH, w = w0 + mm;
+        long long off = -1;
+        if (TR) {
+            if (d < p.Do && 2 * h < p.Ho && 2 * w < p.Wo)
+                off = ((((long long)nb * p.Do + d) * p.Ho + 2 * h + py) * p.Wo + 2 * w + px) * p.cout_stride + p.c_off;
+        } else if (d < p.Do && h < p.Ho && w < p.Wo) {
+            off = ((((long long)nb * p.Do + d) * p.Ho + h) * p.Wo + w) * p.cout_stride + p.c_off;
+        }
+        s_rowoff[tid] = off;
+    }
+
+    hk_wait_vm(n_trail);
     __syncthreads();
+    HK_STAMP(1);
+    // the accumulators start at the bias of their cout (split-K: in the first half only): no bias pass in the epilogue
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float bv = has_bias ? s_cs[j * 16 + r16] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MA; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][j][q] = bv;
+    }
     {
         const int oa = tap_off(0), ob = tap_off(1);
         const int aaddr = a_lane + (tap1 ? ob : oa);
@@ -350,7 +383,8 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     // chunk.  At B_t a wave waits for all its pieces but those of group t - 1 (counted vmcnt); when halo pieces of group t - 1
     // are needed by step t + 1 (UPS = 4: a chunk lasts 3.4 steps), they were issued BEFORE the group's weights and only those
     // weight pieces may stay in flight.
-    int n_prev = 0;                  // pieces of the most recent issue group that may stay in flight at the next barrier
+    int n_prev = n_trail == 4 ? 2 : 0;   // pieces that may stay in flight at the next barrier: those of the most recent issue
+                                         // group; at B_0 the weights of step 2 (step 1's are read behind B_0)
     int hc = 1, hp = 0, hfree = 0;   // next halo chunk to fetch, its next piece, the first step whose group may issue it
     // halo pieces per group: a chunk lasts 6.75 steps (27 entries, UPS 2: 2 + 1 + 1 + 1), 3.4 (UPS 4) or 3 (TR: 12 entries): 3 + 2
     constexpr int H_FIRST = (UPS == 2 && !TR && !DS) ? 2 : 3, H_LATER = (UPS == 2 && !TR && !DS) ? 1 : 3;
@@ -423,8 +457,10 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
 #undef HK_LOAD_B
 #undef HK_MFMA
 #undef HK_SCHED
+    HK_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
+    HK_STAMP(3);
 
     // ---- epilogue: bias, GroupNorm column sums, the 512 x 128 bf16 tile through LDS (128 KB), 16-byte row stores -----
     // accumulator (i, j)[q]: row 16 i + 4 kg + q of the wave's 64, cout 16 j + r16
@@ -491,44 +527,74 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     for (int i = 0; i < MA; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) vbits |= (unsigned)(s_rowoff[wave * 16 * MA + 16 * i + 4 * kg + q] >= 0) << (4 * i + q);
+    // VALU per accumulator: half a v_cvt_pk_bf16_f32 (rows q, q + 1 of one cout share it), one 2-byte LDS write, and for the
+    // column sums one add + one fma; the validity select only in waves that own rows outside the volume (ragged tiles).
+    auto tile_out = [&](auto masked_tag, auto sums_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value, SUMS = decltype(sums_tag)::value;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int col = j * 16 + r16;
-        const int co = n0 + col;
-        const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
-        float s1 = 0.0f, s2 = 0.0f;
+        for (int j = 0; j < NJ; ++j) {
+            const int col = j * 16 + r16;
+            float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < MA; ++i) {
-            bf16_t* trow = s_tile + (wave * 16 * MA + 16 * i + 4 * kg) * BN + col;
+            for (int i = 0; i < MA; ++i) {
+                bf16_t* trow = s_tile + (wave * 16 * MA + 16 * i + 4 * kg) * BNP + col;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float v = acc[i][j][q] + bv;
-                trow[q * BN] = f32_to_bf16(v);
-                if (want_sums) {
-                    const float vm = ((vbits >> (4 * i + q)) & 1u) ? v : 0.0f;
-                    s1 += vm;
-                    s2 += vm * vm;
+                for (int q = 0; q < 4; q += 2) {
+                    const float v0 = acc[i][j][q], v1 = acc[i][j][q + 1];
+                    const uint32_t pk = pack_bf16x2_v(f32x2_t{v0, v1});
+                    trow[q * BNP] = (bf16_t)(pk & 0xffffu);
+                    trow[(q + 1) * BNP] = (bf16_t)(pk >> 16);
+                    if (SUMS) {
+                        const float m0 = (!MASKED || ((vbits >> (4 * i + q)) & 1u)) ? v0 : 0.0f;
+                        const float m1 = (!MASKED || ((vbits >> (4 * i + q + 1)) & 1u)) ? v1 : 0.0f;
+                        s1 += m0;
+                        s2 = __builtin_fmaf(m0, m0, s2);
+                        s1 += m1;
+                        s2 = __builtin_fmaf(m1, m1, s2);
+                    }
+                }
+            }
+            if (SUMS) {
+                s1 += __shfl_xor(s1, 16);
+                s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (kg == 0) {
+                    s_cs[(wave * BN + col) * 2 + 0] = s1;
+                    s_cs[(wave * BN + col) * 2 + 1] = s2;
                 }
             }
         }
-        if (want_sums) {
-            s1 += __shfl_xor(s1, 16);
-            s2 += __shfl_xor(s2, 16);
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (kg == 0) {
-                s_cs[(wave * BN + col) * 2 + 0] = s1;
-                s_cs[(wave * BN + col) * 2 + 1] = s2;
-            }
-        }
+    };
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        const bool ragged = __builtin_amdgcn_ballot_w64(vbits != (1u << (4 * MA)) - 1u) != 0ull;   // wave-uniform
+        if (!want_sums) tile_out(F{}, F{});
+        else if (ragged) tile_out(T{}, T{});
+        else tile_out(F{}, T{});
     }
-    // Every wave wrote exactly its own 16 MA rows of the tile, so it can stream them out without waiting for the other
-    // waves (its LDS writes and reads stay in order): one barrier less, and the waves' store streams are not bunched up
-    // behind it.  p.dbg & 128: the old order (barrier, then rows dealt round-robin to all threads), for A/B timing.
+    HK_STAMP(4);
+    // One barrier (the waves leave the staging together), then the cross-wave column sums, then every wave streams out ITS OWN
+    // 16 MA rows of the tile (it wrote exactly those): nothing follows the last store.
     constexpr int CPR = BN / 8;
     bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
-    const bool wave_local = !(p.dbg & 128);
-    if (wave_local) {
+    __syncthreads();
+    if (want_sums && tid >= NTH - BN) {
+        const int col = tid - (NTH - BN);
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NWAVE; ++q) {
+            t1 += s_cs[(q * BN + col) * 2 + 0];
+            t2 += s_cs[(q * BN + col) * 2 + 1];
+        }
+        const long long slab = (long long)(TR ? 4 : 1) * p.mtiles * CoutPad;   // [class][m-tile][cout_pad], as the gather kernel's
+        const long long tg = (long long)cls * p.mtiles + mt;
+        p.colsum[tg * CoutPad + n0 + col] = t1;
+        p.colsum[slab + tg * CoutPad + n0 + col] = t2;
+    }
+    HK_STAMP(5);
+    {
         constexpr int RPW = 16 * MA;
 #pragma unroll 4
         for (int k = 0; k < RPW * CPR / 64; ++k) {
@@ -537,35 +603,12 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             const long long off = s_rowoff[row];
             const int co = n0 + ch * 8;
             if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
-                const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
+                const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BNP + ch * 8);
                 *reinterpret_cast<uint4*>(y + off + co) = v;
             }
         }
     }
-    __syncthreads();
-    if (want_sums && tid < BN) {
-        float t1 = 0.0f, t2 = 0.0f;
-#pragma unroll
-        for (int q = 0; q < NWAVE; ++q) {
-            t1 += s_cs[(q * BN + tid) * 2 + 0];
-            t2 += s_cs[(q * BN + tid) * 2 + 1];
-        }
-        const long long slab = (long long)(TR ? 4 : 1) * p.mtiles * CoutPad;   // [class][m-tile][cout_pad], as the gather kernel's
-        const long long tg = (long long)cls * p.mtiles + mt;
-        p.colsum[tg * CoutPad + n0 + tid] = t1;
-        p.colsum[slab + tg * CoutPad + n0 + tid] = t2;
-    }
-    if (!wave_local) {
-        for (int c = tid; c < BM * CPR; c += NTH) {
-            const int row = c / CPR, ch = c - row * CPR;
-            const long long off = s_rowoff[row];
-            const int co = n0 + ch * 8;
-            if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
-                const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
-                *reinterpret_cast<uint4*>(y + off + co) = v;
-            }
-        }
-    }
+    HK_STAMP(6);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -698,6 +741,12 @@ extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /*
 
 // Number of device-side errors recorded since the last call with reset != 0 (0 on a healthy run), and the split-K tile of the
 // last one.  SYNCHRONOUS (a 8-byte device-to-host copy): call it where the host reads results anyway.
+extern "C" int ctsi_debug_k32_stamps(unsigned long long* out, int nblocks) {   // timing-only (CTSI_DEBUG_FLAGS & 4096)
+    if (nblocks > HK_NSTAMP) nblocks = HK_NSTAMP;
+    CTSI_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hk_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long)));
+    return CTSI_OK;
+}
+
 extern "C" int ctsi_device_error_status(unsigned int* count, unsigned int* detail, int reset) {
     CTSI_CHECK_ARG(count, "ctsi_device_error_status: null argument");
     unsigned int h[2] = {0u, 0u};

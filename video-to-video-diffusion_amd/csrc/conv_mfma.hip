@@ -18,6 +18,7 @@
 // Epilogue: + bias, optional tanh, bf16 tile transposed through LDS for full-line 16-B stores
 // (or strided fp32 stores for the few-channel output layers), and per-tile column sums
 // (sum, sum of squares) for the GroupNorm that follows every large conv on this path.
+#include <type_traits>
 #include "conv3_halo_common.h"
 #include <string.h>
 #include <stdlib.h>
@@ -365,13 +366,17 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     };
 
     // ---- accumulators -------------------------------------------------------------------------
+    // start value = the bias of the lane's cout (split-K: in the first split only; the splits are summed in split order)
     f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        const float bv = (p.bias != nullptr && co < p.Cout && split == 0) ? p.bias[co] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
 
     // fragment read offsets: row = tile_base + (lane&31); (row>>1)&7 == (lane>>1)&7 for 32-aligned bases
     const int fsw = (lane >> 1) & 7;
@@ -496,50 +501,67 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         vbits[i] = vb;
     }
     if (p.out_mode == 0 && p.act == 0) {
-        // fast path: bf16 NDHWC output staged through LDS, optional column sums
+        // fast path: bf16 NDHWC output staged through LDS, optional column sums.  Per accumulator: half a v_cvt_pk_bf16_f32
+        // (rows r, r + 1 share it), one 2-byte LDS write, one add + one fma for the sums; the validity select only in waves
+        // that own rows outside the volume.
+        auto tile_out = [&](auto masked_tag, auto sums_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value, SUMS = decltype(sums_tag)::value;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = wn * TN * 32 + j * 32 + lcol;
-            const int co = n0 + col;
-            const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
-            float s1 = 0.0f, s2 = 0.0f;
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * TN * 32 + j * 32 + lcol;
+                float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                bf16_t* trow = s_tile + (wm * TM * 32 + i * 32 + 4 * lhi) * BN + col;
+                for (int i = 0; i < TM; ++i) {
+                    bf16_t* trow = s_tile + (wm * TM * 32 + i * 32 + 4 * lhi) * BN + col;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[i][j][r] + bv;
-                    trow[((r & 3) + 8 * (r >> 2)) * BN] = f32_to_bf16(v);
-                    if (want_sums) {
-                        const float vm = ((vbits[i] >> r) & 1u) ? v : 0.0f;
-                        s1 += vm;
-                        s2 += vm * vm;
+                    for (int r = 0; r < 16; r += 2) {
+                        const float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
+                        const uint32_t pk = pack_bf16x2_v(f32x2_t{v0, v1});
+                        const int rr = (r & 3) + 8 * (r >> 2);
+                        trow[rr * BN] = (bf16_t)(pk & 0xffffu);
+                        trow[(rr + 1) * BN] = (bf16_t)(pk >> 16);
+                        if (SUMS) {
+                            const float m0 = (!MASKED || ((vbits[i] >> r) & 1u)) ? v0 : 0.0f;
+                            const float m1 = (!MASKED || ((vbits[i] >> (r + 1)) & 1u)) ? v1 : 0.0f;
+                            s1 += m0;
+                            s2 = __builtin_fmaf(m0, m0, s2);
+                            s1 += m1;
+                            s2 = __builtin_fmaf(m1, m1, s2);
+                        }
+                    }
+                }
+                if (SUMS) {
+                    s1 += __shfl_xor(s1, 32);
+                    s2 += __shfl_xor(s2, 32);
+                    if (lhi == 0) {
+                        s_cs[(wm * BN + col) * 2 + 0] = s1;
+                        s_cs[(wm * BN + col) * 2 + 1] = s2;
                     }
                 }
             }
-            if (want_sums) {
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
-                if (lhi == 0) {
-                    s_cs[(wm * BN + col) * 2 + 0] = s1;
-                    s_cs[(wm * BN + col) * 2 + 1] = s2;
-                }
-            }
-        }
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        bool rg = false;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rg = rg || vbits[i] != 0xffffu;
+        const bool ragged = __builtin_amdgcn_ballot_w64(rg) != 0ull;   // wave-uniform
+        if (!want_sums) tile_out(F{}, F{});
+        else if (ragged) tile_out(T{}, T{});
+        else tile_out(F{}, T{});
     } else {
         // generic path: activation and/or strided fp32 output (few-channel output layers)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * TN * 32 + j * 32 + lcol;
             const int co = n0 + col;
-            const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.0f;
             float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    float v = acc[i][j][r] + bv;
+                    float v = acc[i][j][r];
                     if (p.act == 1) v = tanhf(v);
                     const bool valid = (vbits[i] >> r) & 1u;
                     if (valid) {

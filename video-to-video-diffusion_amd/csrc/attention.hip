@@ -263,31 +263,49 @@ extern "C" int ctsi_attn_pv(const float* depthsum, const double* sums, const flo
 }
 
 // y[n][d][pos][ch] = x + p[n][pos][ch] * (rowsum ? rowsum[n][d][pos][head(ch)] : 1)
+// grid (blocks, n * d): blockIdx.y = one (sample, depth) slice, whose hw * c/8 16-byte chunks line up one to one with the
+// chunks of the sample's p term -- no index arithmetic per chunk in the fast mode (the first version decoded a flat 64-bit
+// chunk index with five 64-bit divisions per 16 bytes).
+template <bool EXACT>
 __global__ void __launch_bounds__(256)
 attn_broadcast_add_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ pterm,
                           const float* __restrict__ rowsum, int heads, bf16_t* __restrict__ y, int c, int d,
-                          long long hw, long long total_chunks) {
+                          int slice_chunks /* hw * c / 8 */) {
     const int cpr = c >> 3;
-    const int hd = c / (heads > 0 ? heads : 1);
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total_chunks;
-         e += (long long)gridDim.x * 256) {
-        const int q = (int)(e % cpr);
-        const long long vox = e / cpr;       // (n*d + dd)*hw + pos
-        const long long pos = vox % hw;
-        const long long nd = vox / hw;
-        const long long nb = nd / d;
-        float f[8], pv[8];
-        unpack8a(*reinterpret_cast<const uint4*>(x + e * 8), f);
-        unpack8a(*reinterpret_cast<const uint4*>(pterm + ((nb * hw + pos) * c + q * 8)), pv);
+    const int slice = blockIdx.y, nb = slice / d;
+    const bf16_t* xs = x + (long long)slice * slice_chunks * 8;
+    bf16_t* ys = y + (long long)slice * slice_chunks * 8;
+    const bf16_t* ps = pterm + (long long)nb * slice_chunks * 8;
+    const float* rs = EXACT ? rowsum + (long long)slice * (slice_chunks / cpr) * heads : nullptr;
+    const int hd8 = EXACT ? (c / heads) >> 3 : 1;            // 8-channel chunks per head
+    const int stride = gridDim.x * 256;
+    auto one = [&](const uint4 xr, const uint4 pr, int e) {
         float scale = 1.0f;
-        if (rowsum) scale = rowsum[vox * heads + (q * 8) / hd];
-        uint4 o;
-        o.x = pack_bf16x2(f[0] + pv[0] * scale, f[1] + pv[1] * scale);
-        o.y = pack_bf16x2(f[2] + pv[2] * scale, f[3] + pv[3] * scale);
-        o.z = pack_bf16x2(f[4] + pv[4] * scale, f[5] + pv[5] * scale);
-        o.w = pack_bf16x2(f[6] + pv[6] * scale, f[7] + pv[7] * scale);
-        *reinterpret_cast<uint4*>(y + e * 8) = o;
+        if (EXACT) {
+            const int pos = e / cpr, q = e - pos * cpr;
+            scale = rs[pos * heads + q / hd8];
+        }
+        const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w}, pw[4] = {pr.x, pr.y, pr.z, pr.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x2_t xv = {__uint_as_float(xw[k] << 16), __uint_as_float(xw[k] & 0xffff0000u)};
+            const f32x2_t pv = {__uint_as_float(pw[k] << 16), __uint_as_float(pw[k] & 0xffff0000u)};
+            o[k] = pack_bf16x2_v(xv + pv * scale);
+        }
+        *reinterpret_cast<uint4*>(ys + (long long)e * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    int e = blockIdx.x * 256 + threadIdx.x;
+    for (; e + stride < slice_chunks; e += 2 * stride) {     // two independent chunks in flight
+        const uint4 x0 = *reinterpret_cast<const uint4*>(xs + (long long)e * 8);
+        const uint4 p0 = *reinterpret_cast<const uint4*>(ps + (long long)e * 8);
+        const uint4 x1 = *reinterpret_cast<const uint4*>(xs + (long long)(e + stride) * 8);
+        const uint4 p1 = *reinterpret_cast<const uint4*>(ps + (long long)(e + stride) * 8);
+        one(x0, p0, e);
+        one(x1, p1, e + stride);
     }
+    if (e < slice_chunks)
+        one(*reinterpret_cast<const uint4*>(xs + (long long)e * 8), *reinterpret_cast<const uint4*>(ps + (long long)e * 8), e);
 }
 
 extern "C" int ctsi_attn_broadcast_add(const void* x, const void* p, const float* rowsum, int heads, void* y,
@@ -296,13 +314,18 @@ extern "C" int ctsi_attn_broadcast_add(const void* x, const void* p, const float
     CTSI_CHECK_ARG(c % 8 == 0, "ctsi_attn_broadcast_add: c=%d must be a multiple of 8", c);
     if (rowsum) CTSI_CHECK_ARG(heads > 0 && c % heads == 0 && (c / heads) % 8 == 0,
                                "ctsi_attn_broadcast_add: exact mode needs head_dim %% 8 == 0");
-    const long long total = (long long)n * d * h * w * (c / 8);
-    long long blocks = (total + 256 * 4 - 1) / (256 * 4);
-    if (blocks > 4096) blocks = 4096;
+    const long long slice = (long long)h * w * (c / 8);
+    CTSI_CHECK_ARG(slice < (1ll << 30) && (long long)n * d < 65536, "ctsi_attn_broadcast_add: slice too large");
+    long long blocks = (slice + 256 * 2 - 1) / (256 * 2);
+    const long long cap = (4096 + (long long)n * d - 1) / ((long long)n * d);   // ~4096 blocks over all slices
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(attn_broadcast_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (const bf16_t*)p, rowsum, heads, (bf16_t*)y, c, d, (long long)h * w,
-                       total);
+    if (rowsum)
+        hipLaunchKernelGGL(attn_broadcast_add_kernel<true>, dim3((unsigned)blocks, n * d), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (const bf16_t*)p, rowsum, heads, (bf16_t*)y, c, d, (int)slice);
+    else
+        hipLaunchKernelGGL(attn_broadcast_add_kernel<false>, dim3((unsigned)blocks, n * d), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (const bf16_t*)p, rowsum, heads, (bf16_t*)y, c, d, (int)slice);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

@@ -419,7 +419,20 @@ channel_sum_partial_kernel(const bf16_t* __restrict__ x, long long rows, int c, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = 0.0f;
     if (rl < rows_par) {
-        for (long long v = v0 + rl; v < v1; v += rows_par) {
+        long long v = v0 + rl;
+        for (; v + 3ll * rows_par < v1; v += 4ll * rows_par) {   // four rows in flight per thread, added in row order
+            uint4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(x + (v + (long long)u * rows_par) * c_stride + q * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                t_unpack8(raw[u], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += f[k];
+            }
+        }
+        for (; v < v1; v += rows_par) {
             float f[8];
             t_unpack8(*reinterpret_cast<const uint4*>(x + v * c_stride + q * 8), f);
 #pragma unroll
@@ -435,13 +448,32 @@ channel_sum_partial_kernel(const bf16_t* __restrict__ x, long long rows, int c, 
         partial[(long long)blockIdx.x * c + ch] = t;
     }
 }
+// one block = 16 channels x 16 lanes over the row blocks (one serial thread per channel took 50-100 us for the 432 partial rows
+// of a 4 x 48^3 tensor); every lane sums its strided subset in order, lane 0 adds the 16 lane sums in order: a fixed order
 __global__ void __launch_bounds__(256)
 channel_sum_final_kernel(const float* __restrict__ partial, int blocks, int c, float* __restrict__ out, float scale) {
-    const int ch = blockIdx.x * 256 + threadIdx.x;
-    if (ch >= c) return;
-    float t = 0.0f;
-    for (int b = 0; b < blocks; ++b) t += partial[(long long)b * c + ch];
-    out[ch] = t * scale;
+    __shared__ float s_part[16][17];
+    const int cl = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+    if (ch < c) {
+        int b = r;
+        for (; b + 48 < blocks; b += 64) {
+            t0 += partial[(long long)b * c + ch];
+            t1 += partial[(long long)(b + 16) * c + ch];
+            t2 += partial[(long long)(b + 32) * c + ch];
+            t3 += partial[(long long)(b + 48) * c + ch];
+        }
+        for (; b < blocks; b += 16) t0 += partial[(long long)b * c + ch];
+    }
+    s_part[r][cl] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (r == 0 && ch < c) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s_part[k][cl];
+        out[ch] = t * scale;
+    }
 }
 #define CHSUM_ROWS 1024
 extern "C" size_t ctsi_channel_sum_workspace_floats(long long rows, int c) {
@@ -456,7 +488,7 @@ extern "C" int ctsi_channel_sum(const void* x, long long rows, int c, int c_stri
     hipLaunchKernelGGL(channel_sum_partial_kernel, dim3((unsigned)blocks), dim3(256), (size_t)rows_par * c * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)x, rows, c, c_stride, workspace, (long long)CHSUM_ROWS);
     CTSI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((c + 15) / 16), dim3(256), 0, (hipStream_t)stream, workspace,
                        (int)blocks, c, out, scale);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;

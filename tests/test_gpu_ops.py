@@ -450,18 +450,23 @@ def test_groupnorm_statistics_are_bit_stable(G):
         assert torch.equal(s_, runs[0])
 
 
-def test_groupnorm_apply_variants(G):
+@pytest.mark.parametrize("shape", [(2, 64, 3, 5, 7), (1, 192, 2, 3, 5), (1, 128, 6, 24, 32)],
+                         ids=["c64-small", "c192-lds-coefficients", "c128-grid-stride"])
+def test_groupnorm_apply_variants(G, shape):
+    """Every instantiation of gn_apply_kernel<SILU_PRE, TB, RES, SILU_POST, CONSTQ>: the 16 option combinations on a tensor
+    whose grid stride is a multiple of the row's chunk count (coefficients in registers), on one where it is not (c = 192: 24
+    chunks per row and fewer than 3 blocks -- the LDS path), and on one that every thread walks several times."""
     E, ctx = G.E, G.ctx()
-    n, c, d, h, w = 2, 64, 3, 5, 7
+    n, c, d, h, w = shape
     x = bf16_round(formula_input((n, c, d, h, w), 11) * 2 + 0.5)
     res = bf16_round(formula_input((n, c, d, h, w), 12))
     gnm = torch.nn.GroupNorm(8, c)
     with torch.no_grad():
         gnm.weight.copy_(1 + 0.2 * formula_input((c,), 13))
         gnm.bias.copy_(0.1 * formula_input((c,), 14))
-    tb = formula_input((3 * n, 80), 15)    # 3 "steps", row stride 80, offset 16
-    for silu_pre, use_tb, use_res, silu_post, step in [(1, 0, 0, 0, None), (1, 1, 0, 0, 2), (0, 0, 1, 1, None),
-                                                        (0, 0, 0, 0, None)]:
+    tb = formula_input((3 * n, c + 16), 15)    # 3 "steps", row stride c + 16, offset 16
+    combos = [(a, b_, c_, d_, 2 if b_ else None) for a in (0, 1) for b_ in (0, 1) for c_ in (0, 1) for d_ in (0, 1)]
+    for silu_pre, use_tb, use_res, silu_post, step in combos:
         with ctx.scope():
             prog = E.Program(ctx)
             a = G.to_act(prog, x)
@@ -472,7 +477,7 @@ def test_groupnorm_apply_variants(G):
             tbd = tb.to(ctx.device)
             sp = torch.tensor([step or 0], dtype=torch.int32, device=ctx.device)
             y = prog.gn_apply(a, slot, gnm, silu_pre=bool(silu_pre), tbias=tbd if use_tb else None, tbias_off=16,
-                              tbias_stride=80, step_ptr=sp if step is not None else None, residual=r,
+                              tbias_stride=c + 16, step_ptr=sp if step is not None else None, residual=r,
                               silu_post=bool(silu_post))
             prog.finalize_layout()
             prog.run()

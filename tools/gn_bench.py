@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 E = importlib.import_module("video-to-video-diffusion_amd.engine")
 dev = torch.device("cuda", 0)
 ctx = E.Ctx.get(dev)
-for (c, d, h, w) in ((128, 48, 128, 128), (256, 48, 64, 64)):
+for (c, d, h, w) in ((128, 48, 128, 128), (256, 48, 64, 64), (128, 48, 512, 512), (256, 48, 256, 256)):
     for res in (False, True):
         with ctx.scope():
             prog = E.Program(ctx)

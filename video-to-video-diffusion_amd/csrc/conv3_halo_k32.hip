@@ -604,7 +604,13 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             const int co = n0 + ch * 8;
             if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
                 const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BNP + ch * 8);
-                *reinterpret_cast<uint4*>(y + off + co) = v;
+                if (p.nt_store) {     // streaming (non-temporal) stores: see ctsi_conv_fwd
+                    typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+                    const u4_t w4 = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(w4, reinterpret_cast<u4_t*>(y + off + co));
+                } else {
+                    *reinterpret_cast<uint4*>(y + off + co) = v;
+                }
             }
         }
     }

@@ -1353,6 +1353,14 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         h.ds = p->ds;
         h.Cout = p->d.cout; h.CoutPad = p->CoutPad;
         h.cout_stride = o->cout_stride; h.c_off = o->c_off;
+        {   // k32 kernel: streaming (non-temporal) output stores for tensors the next pass cannot find in a cache anyway (>= 128 MB:
+            // the U-Net's 48 x 128^2 level, the VAE's full-resolution levels): the tile's 128 KB no longer displace halos and
+            // weight slabs from the XCD's 4 MB L2 (128->128 @48x128^2 1318 -> 1343 TFLOP/s; step 25.90 -> 25.78 ms with the
+            // following gn_apply 0.04-0.1 ms slower).  CTSI_CONV_NT_STORE=0 / 1 overrides.
+            static const char* nts = getenv("CTSI_CONV_NT_STORE");
+            const long long out_bytes = (long long)p->d.n * p->Do * p->Ho * p->Wo * o->cout_stride * 2;
+            h.nt_store = nts ? atoi(nts) != 0 : out_bytes >= (128ll << 20);
+        }
         {   // n-major block order (one n-tile's 3.5 MB weight slab at a time per XCD instead of all of them: the 48x32x32 /
             // 512-cout layers move 508 MB of HBM traffic per launch against 114 MB algorithmic because 14 MB of weights
             // thrash the 4 MB L2).  Interleaved timing shows no speed difference (1214 vs 1211 TFLOP/s), so it stays opt-in.

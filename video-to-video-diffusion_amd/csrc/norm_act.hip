@@ -5,6 +5,7 @@
 // Statistics path: per-tile column sums (conv epilogue or gn_colsum_kernel) -> gn_finalize_kernel
 // (fp64 (sum, sumsq) per (sample, group)) -> gn_apply_kernel.
 #include "ctsi_internal.h"
+#include <stdlib.h>
 
 #define GN_TILE_ROWS 512
 
@@ -198,12 +199,32 @@ extern "C" int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c,
     return CTSI_OK;
 }
 
+// 16-byte accesses, optionally non-temporal (tensors far larger than the Infinity Cache: streamed once)
+typedef unsigned int gn_u4_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 gn_ld(const bf16_t* p) {
+    if (NT) {
+        const gn_u4_t v = __builtin_nontemporal_load(reinterpret_cast<const gn_u4_t*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const uint4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void gn_st(bf16_t* p, const uint4 v) {
+    if (NT) {
+        const gn_u4_t w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<gn_u4_t*>(p));
+    } else {
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+}
+
 // ---- apply --------------------------------------------------------------------------------------
 // grid: (blocks_per_sample, n); block 256.  The four options are template parameters: with run-time flags the compiler
 // if-converted both SiLU sites into unconditional code (2 exp + 2 rcp per element and a select chain: ~25 VALU instructions
 // per element, 2.3 TB/s each way -- VALU-bound, not HBM-bound).  CONSTQ: the grid stride is a multiple of the row's chunk
 // count, so a thread meets the same 8 channels every iteration and keeps their scale / shift / time bias in registers.
-template <bool SILU_PRE, bool TB, bool RES, bool SILU_POST, bool CONSTQ>
+template <bool SILU_PRE, bool TB, bool RES, bool SILU_POST, bool CONSTQ, bool NT>
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const double* __restrict__ sums,
                 const float* __restrict__ gamma, const float* __restrict__ beta, int c, long long vox,
@@ -272,15 +293,15 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const doub
             if (SILU_POST) v = silu2_f(v);
             o[j] = pack_bf16x2_v(v);
         }
-        *reinterpret_cast<uint4*>(yb + ee * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        gn_st<NT>(yb + ee * 8, make_uint4(o[0], o[1], o[2], o[3]));
     };
     for (; e + (U - 1) * stride < total; e += U * stride) {
         uint4 raw[U], rraw[U];
         int qs[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            raw[u] = *reinterpret_cast<const uint4*>(xb + (e + u * stride) * 8);
-            rraw[u] = RES ? *reinterpret_cast<const uint4*>(rb + (e + u * stride) * 8) : make_uint4(0, 0, 0, 0);
+            raw[u] = gn_ld<NT>(xb + (e + u * stride) * 8);
+            rraw[u] = RES ? gn_ld<NT>(rb + (e + u * stride) * 8) : make_uint4(0, 0, 0, 0);
             qs[u] = q;
             if (!CONSTQ) q = (q + dq >= cpr) ? q + dq - cpr : q + dq;
         }
@@ -288,8 +309,8 @@ gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const doub
         for (int u = 0; u < U; ++u) one(raw[u], rraw[u], e + u * stride, qs[u]);
     }
     for (; e < total; e += stride) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(xb + e * 8);
-        const uint4 rraw = RES ? *reinterpret_cast<const uint4*>(rb + e * 8) : make_uint4(0, 0, 0, 0);
+        const uint4 raw = gn_ld<NT>(xb + e * 8);
+        const uint4 rraw = RES ? gn_ld<NT>(rb + e * 8) : make_uint4(0, 0, 0, 0);
         one(raw, rraw, e, q);
         if (!CONSTQ) q = (q + dq >= cpr) ? q + dq - cpr : q + dq;
     }
@@ -299,10 +320,10 @@ typedef void (*gn_apply_fn)(const bf16_t*, bf16_t*, const double*, const float*,
                             float, const float*, int, const int*, int, const bf16_t*);
 template <int I>
 static gn_apply_fn gn_apply_pick(int idx) {
-    if constexpr (I >= 32) {
+    if constexpr (I >= 64) {
         return nullptr;
     } else {
-        if (idx == I) return gn_apply_kernel<(I & 1) != 0, (I & 2) != 0, (I & 4) != 0, (I & 8) != 0, (I & 16) != 0>;
+        if (idx == I) return gn_apply_kernel<(I & 1) != 0, (I & 2) != 0, (I & 4) != 0, (I & 8) != 0, (I & 16) != 0, (I & 32) != 0>;
         return gn_apply_pick<I + 1>(idx);
     }
 }
@@ -327,7 +348,10 @@ extern "C" int ctsi_gn_apply(const void* x, void* y, const double* sums, const f
     if (blocks >= need) blocks -= blocks % need;
     const bool constq = (blocks * 256) % cpr == 0;
     const size_t lds = (size_t)c * 3 * sizeof(float);
-    const int idx = (silu_pre ? 1 : 0) | (tbias ? 2 : 0) | (residual ? 4 : 0) | (silu_post ? 8 : 0) | (constq ? 16 : 0);
+    // tensors beyond the Infinity Cache (256 MB) are streamed with non-temporal accesses (CTSI_GN_NT=0 / 1 overrides)
+    static const char* nt_env = getenv("CTSI_GN_NT");
+    const bool nt = nt_env ? atoi(nt_env) != 0 : (long long)n * vox * c * 2 > (512ll << 20);
+    const int idx = (silu_pre ? 1 : 0) | (tbias ? 2 : 0) | (residual ? 4 : 0) | (silu_post ? 8 : 0) | (constq ? 16 : 0) | (nt ? 32 : 0);
     hipLaunchKernelGGL(gn_apply_pick<0>(idx), dim3((unsigned)blocks, n), dim3(256), lds, (hipStream_t)stream,
                        (const bf16_t*)x, (bf16_t*)y, sums, gamma, beta, c, vox, (long long)d_stat * h * w, groups, eps,
                        tbias, tbias_stride, step_ptr, n, (const bf16_t*)residual);

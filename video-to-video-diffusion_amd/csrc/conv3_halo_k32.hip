@@ -74,7 +74,9 @@ __device__ __forceinline__ void hk_wait_vm(int allowed) {   // wave-uniform `all
         case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); break;
     }
 }
 
@@ -354,7 +356,16 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         s_rowoff[tid] = off;
     }
 
-    hk_wait_vm(n_trail);
+    // 3x3x3 form: step 0 and the fragment loads it runs ahead read taps 0-5 (k_d = 0), i.e. halo depth slices 0 .. TD - 1 only;
+    // the pieces that hold slices TD, TD + 1 (the youngest halo pieces of a wave, issued before the weights of steps 1-2) may
+    // stay in flight as well: B_0 waits for everything but the weights of step 2, and slice TD is first read behind B_1.
+    int n_late = 0;
+    if constexpr (!TR && !DS) {
+        constexpr int NEED = (Cfg::TD * HH * HW + 31) / 32;
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) n_late += (wave + NWAVE * i >= NEED && wave + NWAVE * i < HALO_INSTR) ? 1 : 0;
+    }
+    hk_wait_vm(n_trail == 4 ? n_trail + n_late : n_trail);
     __syncthreads();
     HK_STAMP(1);
     // the accumulators start at the bias of their cout (split-K: in the first half only): no bias pass in the epilogue

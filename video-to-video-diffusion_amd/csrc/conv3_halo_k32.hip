@@ -184,6 +184,33 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
                                        (long long)cbase * TAPS * p.CoutPad * 32, 0x7fffffffu);
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr3_t)smem;
 
+    const int C1 = p.C1, C2 = p.C2, CoutPad = p.CoutPad;
+    const int Q = nchunks * TAPS;                            // (chunk, tap) entries
+    const int S = (Q + STEP_TAPS - 1) / STEP_TAPS;           // steps (the packed image is zero-padded to whole steps)
+    // weights of step s = STEP_TAPS entries x TAP_BYTES = 16 pieces of 1 KB: wave w copies pieces w and 8 + w
+    const unsigned w_voff = (unsigned)lane * 16u;
+    auto issue_weights = [&](int s) {
+        const unsigned slot = lds0 + OFF_W + (s % NWS) * WSLOT_BYTES;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int piece = wave + NWAVE * k;
+            constexpr int PPT = TAP_BYTES / 1024;            // pieces per entry
+            const int e = piece / PPT, quarter = piece % PPT;
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((s * STEP_TAPS + e) * CoutPad) * 32 + quarter * 1024);
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(slot + piece * 1024));
+            h3_dma16(rsw, dst, w_voff, soff);
+        }
+    };
+
+    // first of the prologue (see below): the bias row and the weights of step 0 need no per-lane halo arithmetic -- they fly while it runs
+    const bool has_bias = p.bias != nullptr && khalf == 0;
+    if (has_bias && wave == 0) {
+        const int left = p.Cout - n0;
+        const v4i_t rsb = h3_make_rsrc(p.bias + n0, (unsigned)(left > 0 ? left * 4 : 0));
+        h3_dma16(rsb, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + OFF_CS)), (unsigned)lane * 16u, 0u);
+    }
+    if (S > 0) issue_weights(0);
+
     // halo DMA: piece j = wave + NWAVE * i covers halo voxels 32 j .. 32 j + 31; lane -> voxel 32 j + lane / 2, 16-byte half lane & 1
     int hrel[NPIECE];
 #pragma unroll
@@ -202,9 +229,6 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         }
     }
     const unsigned hq16 = (unsigned)((lane & 1) * 16);
-    const int C1 = p.C1, C2 = p.C2, CoutPad = p.CoutPad;
-    const int Q = nchunks * TAPS;                            // (chunk, tap) entries
-    const int S = (Q + STEP_TAPS - 1) / STEP_TAPS;           // steps (the packed image is zero-padded to whole steps)
 
     auto issue_halo = [&](int cc, int i) -> int {
         const int j = wave + NWAVE * i;
@@ -230,21 +254,6 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             h3_dma16(rs1, dst, voff, soff);
         return 1;
     };
-    // weights of step s = STEP_TAPS entries x TAP_BYTES = 16 pieces of 1 KB: wave w copies pieces w and 8 + w
-    const unsigned w_voff = (unsigned)lane * 16u;
-    auto issue_weights = [&](int s) {
-        const unsigned slot = lds0 + OFF_W + (s % NWS) * WSLOT_BYTES;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int piece = wave + NWAVE * k;
-            constexpr int PPT = TAP_BYTES / 1024;            // pieces per entry
-            const int e = piece / PPT, quarter = piece % PPT;
-            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((s * STEP_TAPS + e) * CoutPad) * 32 + quarter * 1024);
-            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(slot + piece * 1024));
-            h3_dma16(rsw, dst, w_voff, soff);
-        }
-    };
-
     // fragment addressing: lane -> row r16 = lane & 15 of the 16-row operand tile, k group kg = lane >> 4:
     // kg >> 1 = which of the unit's two taps, kg & 1 = which 8 of the tap's 16 channels
     const int r16 = lane & 15, kg = lane >> 4;
@@ -327,13 +336,6 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     // read as 0 through the buffer's range check), weights of step 0, halo of chunk 0 -- and BEHIND them the weights of steps
     // 1 and 2, which may stay in flight when the loop starts: every CU runs its prologue at the same time and that burst is
     // HBM-bound (13-14 k cycles per tile with all 87 KB awaited, tools/k32_stamps.py), so the loop starts on the first 55 KB.
-    const bool has_bias = p.bias != nullptr && khalf == 0;
-    if (has_bias && wave == 0) {
-        const int left = p.Cout - n0;
-        const v4i_t rsb = h3_make_rsrc(p.bias + n0, (unsigned)(left > 0 ? left * 4 : 0));
-        h3_dma16(rsb, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + OFF_CS)), (unsigned)lane * 16u, 0u);
-    }
-    if (S > 0) issue_weights(0);
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) issue_halo(0, i);
     int n_trail = 0;                 // pieces of steps 1 and 2 (the youngest of this wave)
@@ -356,11 +358,11 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         s_rowoff[tid] = off;
     }
 
-    // 3x3x3 form: step 0 and the fragment loads it runs ahead read taps 0-5 (k_d = 0), i.e. halo depth slices 0 .. TD - 1 only;
+    // 3x3x3 and Downsample forms (taps ordered k_d first): step 0 and the fragment loads it runs ahead read taps with k_d = 0, i.e. halo depth slices 0 .. TD - 1 only;
     // the pieces that hold slices TD, TD + 1 (the youngest halo pieces of a wave, issued before the weights of steps 1-2) may
     // stay in flight as well: B_0 waits for everything but the weights of step 2, and slice TD is first read behind B_1.
     int n_late = 0;
-    if constexpr (!TR && !DS) {
+    if constexpr (!TR) {
         constexpr int NEED = (Cfg::TD * HH * HW + 31) / 32;
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) n_late += (wave + NWAVE * i >= NEED && wave + NWAVE * i < HALO_INSTR) ? 1 : 0;

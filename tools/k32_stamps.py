@@ -40,7 +40,7 @@ used = buf[:, 0] != 0
 s = buf[used].astype(np.int64)
 print(f"{used.sum()} blocks recorded")
 t = s[:, :7] - s[:, :1]
-names = ["entry->loop start (prologue)", "loop", "loop end->barrier", "LDS staging + sums", "barrier + column sums", "row stores issued"]
+names = ["entry->loop start (prologue)", "loop", "loop end->barrier", "LDS staging + sums", "row stores issued", "barrier + cross-wave column sums"]
 for k in range(6):
     dk = t[:, k + 1] - t[:, k]
     print(f"{names[k]:32s} mean {dk.mean():9.0f}  p10 {np.percentile(dk, 10):9.0f}  p90 {np.percentile(dk, 90):9.0f} ticks")

@@ -634,32 +634,43 @@ conv_gather_mfma_kernel(const ConvKParams p) {
                 hreg[it] = (off >= 0 && co < p.Cout) ? *reinterpret_cast<const uint4*>(p.gn_x + off + co)
                                                      : make_uint4(0, 0, 0, 0);
             }
+            // NTH is a multiple of the row's chunk count: a thread meets the same 8 couts in every iteration and keeps their scale /
+            // shift in registers (4 16-byte LDS reads per thread instead of 16 scalar ones per piece, whose 32-byte lane stride put
+            // two lanes on every bank: most of the 34-48 % LDS bank conflicts the counters showed for the 1x1x1 tails)
+            static_assert(NTH % CPR == 0, "a thread's chunk must not depend on the iteration");
+            const int cc0 = tid % CPR;
+            float gsc[8], gsh[8];
+            *reinterpret_cast<float4*>(gsc) = *reinterpret_cast<const float4*>(s_cs + cc0 * 8);
+            *reinterpret_cast<float4*>(gsc + 4) = *reinterpret_cast<const float4*>(s_cs + cc0 * 8 + 4);
+            *reinterpret_cast<float4*>(gsh) = *reinterpret_cast<const float4*>(s_cs + BN + cc0 * 8);
+            *reinterpret_cast<float4*>(gsh + 4) = *reinterpret_cast<const float4*>(s_cs + BN + cc0 * 8 + 4);
+            auto tail = [&](auto silu_tag) {
+                constexpr bool SILU = decltype(silu_tag)::value;
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int c = tid + it * NTH;
-                const int row = c / CPR, cc = c - row * CPR;
-                const long long off = s_rowoff[row];
-                const int co = n0 + cc * 8;
-                if (off >= 0 && co < p.Cout) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + cc * 8);
-                    const uint4 h = hreg[it];
-                    const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, rw[4] = {v.x, v.y, v.z, v.w};
-                    uint32_t ow[4];
+                for (int it = 0; it < ITER; ++it) {
+                    const int c = tid + it * NTH;
+                    const int row = c / CPR, cc = c - row * CPR;
+                    const long long off = s_rowoff[row];
+                    const int co = n0 + cc * 8;
+                    if (off >= 0 && co < p.Cout) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + cc * 8);
+                        const uint4 h = hreg[it];
+                        const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, rw[4] = {v.x, v.y, v.z, v.w};
+                        uint32_t ow[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int ch = cc * 8 + 2 * k;
-                        float a = __uint_as_float(hw[k] << 16) * s_cs[ch] + s_cs[BN + ch] + __uint_as_float(rw[k] << 16);
-                        float b = __uint_as_float(hw[k] & 0xffff0000u) * s_cs[ch + 1] + s_cs[BN + ch + 1] +
-                                  __uint_as_float(rw[k] & 0xffff0000u);
-                        if (p.gn_silu) {
-                            a = silu_f(a);
-                            b = silu_f(b);
+                        for (int k = 0; k < 4; ++k) {
+                            f32x2_t a = {__uint_as_float(hw[k] << 16), __uint_as_float(hw[k] & 0xffff0000u)};
+                            a = a * f32x2_t{gsc[2 * k], gsc[2 * k + 1]} + f32x2_t{gsh[2 * k], gsh[2 * k + 1]} +
+                                f32x2_t{__uint_as_float(rw[k] << 16), __uint_as_float(rw[k] & 0xffff0000u)};
+                            if (SILU) a = silu2_f(a);
+                            ow[k] = pack_bf16x2_v(a);
                         }
-                        ow[k] = pack_bf16x2(a, b);
+                        *reinterpret_cast<uint4*>(y + off + co) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
                     }
-                    *reinterpret_cast<uint4*>(y + off + co) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
                 }
-            }
+            };
+            if (p.gn_silu) tail(std::true_type{});
+            else tail(std::false_type{});
         } else {
             for (int c = tid; c < BM * CPR; c += NTH) {
                 const int row = c / CPR, cc = c - row * CPR;

@@ -44,7 +44,7 @@ struct H32Cfg {
     static constexpr int OFF_CS = OFF_ROW + BM * 8;
     static constexpr int LDS_BYTES = OFF_CS + WM * BN * 8;  // <4,2,32>: 159744 <= 163840
     static constexpr int NPIECE = (HALO_INSTR + 7) / 8;    // halo DMA instructions per wave and chunk (issued at g < NPIECE)
-    static_assert(WM * WN == 8 && BM % (TM * 32) == 0 && 32 % TW == 0 && NPIECE <= 9 && LDS_BYTES <= 160 * 1024 &&
+    static_assert(WM * WN == 8 && BM % (TM * 32) == 0 && 32 % TW == 0 && (TW == 32 || TH % 2 == 0) && NPIECE <= 9 && LDS_BYTES <= 160 * 1024 &&
                       BM * BN * 2 <= OFF_W, "unsupported tile");
 };
 
@@ -80,8 +80,14 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
     const int tW = r0 - tH * p.tilesW;
     const int d0 = tD * TD, h0 = tH * TH, w0 = tW * TW;
 
+    // 16-wide tiles: an A tile of 32 rows is two W-lines, HW = 18 halo voxels apart -- the second line's rows would sit 2 voxels
+    // off the 16-voxel bank pattern of the first (42 % LDS bank conflicts in conv3_halo32_kernel<3,4,16,3,1>).  Its rows are
+    // therefore ROTATED by 2: row 16 + r of a tile holds voxel (r + 14) % 16 of the odd line, which reads halo voxel
+    // v0 + 18 + (r + 14) % 16 = v0 + 16 + r (+ 16 for r < 2): the bank pattern of 32 consecutive voxels.  The same rotation
+    // in the row-offset table is all the epilogue needs (column sums do not depend on the row order).
+    auto rot16 = [](int m, int line) -> int { return (TW == 16 && (line & 1)) ? ((m + 14) & 15) : m; };
     if (tid < BM) {   // row = line*TW + m, line = ld*TH + lh
-        const int mm = tid % TW, line = tid / TW;
+        const int line = tid / TW, mm = rot16(tid % TW, line);
         const int d = d0 + line / TH, h = h0 + line % TH, w = w0 + mm;
         long long off = -1;
         if (d < p.Do && h < p.Ho && w < p.Wo)
@@ -146,7 +152,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {                           // A tile = rows [(wm*TM + i)*32, +32) = LPT whole W-lines
         const int line = (wm * TM + i) * LPT + r / TW;
-        vline[i] = ((line / TH) * HH + (line % TH)) * HW + r % TW;
+        vline[i] = ((line / TH) * HH + (line % TH)) * HW + rot16(r % TW, line);
     }
     const int rowb = wn * (TN * 32) + r;
     const int b_off = rowb * 64 + ((hk ^ ((rowb >> 2) & 3)) << 4);   // k-step 0; k-step 1 = ^32; n-tile 1 = +2048

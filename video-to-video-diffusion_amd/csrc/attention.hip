@@ -278,7 +278,7 @@ attn_broadcast_add_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict
     const bf16_t* ps = pterm + (long long)nb * slice_chunks * 8;
     const float* rs = EXACT ? rowsum + (long long)slice * (slice_chunks / cpr) * heads : nullptr;
     const int hd8 = EXACT ? (c / heads) >> 3 : 1;            // 8-channel chunks per head
-    const int stride = gridDim.x * 256;
+    const int stride = 256;                                  // a block walks its own contiguous 512 chunks (see ctsi_gn_apply)
     auto one = [&](const uint4 xr, const uint4 pr, int e) {
         float scale = 1.0f;
         if (EXACT) {
@@ -295,16 +295,15 @@ attn_broadcast_add_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict
         }
         *reinterpret_cast<uint4*>(ys + (long long)e * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     };
-    int e = blockIdx.x * 256 + threadIdx.x;
-    for (; e + stride < slice_chunks; e += 2 * stride) {     // two independent chunks in flight
+    int e = blockIdx.x * 512 + threadIdx.x;
+    if (e + stride < slice_chunks) {                         // two independent chunks in flight
         const uint4 x0 = *reinterpret_cast<const uint4*>(xs + (long long)e * 8);
         const uint4 p0 = *reinterpret_cast<const uint4*>(ps + (long long)e * 8);
         const uint4 x1 = *reinterpret_cast<const uint4*>(xs + (long long)(e + stride) * 8);
         const uint4 p1 = *reinterpret_cast<const uint4*>(ps + (long long)(e + stride) * 8);
         one(x0, p0, e);
         one(x1, p1, e + stride);
-    }
-    if (e < slice_chunks)
+    } else if (e < slice_chunks)
         one(*reinterpret_cast<const uint4*>(xs + (long long)e * 8), *reinterpret_cast<const uint4*>(ps + (long long)e * 8), e);
 }
 
@@ -316,10 +315,7 @@ extern "C" int ctsi_attn_broadcast_add(const void* x, const void* p, const float
                                "ctsi_attn_broadcast_add: exact mode needs head_dim %% 8 == 0");
     const long long slice = (long long)h * w * (c / 8);
     CTSI_CHECK_ARG(slice < (1ll << 30) && (long long)n * d < 65536, "ctsi_attn_broadcast_add: slice too large");
-    long long blocks = (slice + 256 * 2 - 1) / (256 * 2);
-    const long long cap = (4096 + (long long)n * d - 1) / ((long long)n * d);   // ~4096 blocks over all slices
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
+    const long long blocks = (slice + 511) / 512;
     if (rowsum)
         hipLaunchKernelGGL(attn_broadcast_add_kernel<true>, dim3((unsigned)blocks, n * d), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)x, (const bf16_t*)p, rowsum, heads, (bf16_t*)y, c, d, (int)slice);

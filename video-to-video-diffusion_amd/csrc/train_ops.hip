@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256)
 gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, const double* __restrict__ sums,
                     const float* __restrict__ gamma, const float* __restrict__ s12,
                     const bf16_t* __restrict__ add, bf16_t* __restrict__ dx, int c, long long vox, int groups,
-                    float eps) {
+                    float eps, int contig) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* s_rs = reinterpret_cast<float*>(smem_raw);
     float* s_mr = s_rs + c;
@@ -276,8 +276,10 @@ gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, 
     const bf16_t* xb = x + (long long)nb * vox * c;
     const bf16_t* ab = ADD ? add + (long long)nb * vox * c : nullptr;
     bf16_t* ob = dx + (long long)nb * vox * c;
-    const long long stride = (long long)gridDim.x * 256;
-    const long long e0 = (long long)blockIdx.x * 256 + tid;
+    // contig: one contiguous batch of 2 x 256 chunks per block, blocks in address order (see ctsi_gn_apply); else grid-stride
+    const long long stride = contig ? 256 : (long long)gridDim.x * 256;
+    const long long e0 = (contig ? (long long)blockIdx.x * 512 : (long long)blockIdx.x * 256) + tid;
+    const long long total_end = contig && (long long)(blockIdx.x + 1) * 512 < total ? (long long)(blockIdx.x + 1) * 512 : total;
     const int q = (int)(e0 % cpr);                       // stride % cpr == 0: the same chunk every iteration
     float rs[8], mr[8], ag[8], b1[8], b2[8];
 #pragma unroll
@@ -304,7 +306,7 @@ gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, 
     };
     constexpr int U = 2;                                 // independent iterations in flight (4-6 16-byte loads)
     long long e = e0;
-    for (; e + (U - 1) * stride < total; e += U * stride) {
+    for (; e + (U - 1) * stride < total_end; e += U * stride) {
         uint4 gr[U], xr[U], ar[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -315,7 +317,7 @@ gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, 
 #pragma unroll
         for (int u = 0; u < U; ++u) one(gr[u], xr[u], ar[u], e + u * stride);
     }
-    for (; e < total; e += stride)
+    for (; e < total_end; e += stride)
         one(*reinterpret_cast<const uint4*>(gb + e * 8), *reinterpret_cast<const uint4*>(xb + e * 8),
             ADD ? *reinterpret_cast<const uint4*>(ab + e * 8) : make_uint4(0, 0, 0, 0), e);
 }
@@ -379,7 +381,11 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
     const long long total = vox * cpr;
     long long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    {   // grid stride = a multiple of the chunks per voxel row (cpr <= 256: one block's 256 threads times need)
+    int contig = 0;
+    if (256 % cpr == 0) {   // contiguous batches of 512 chunks per block
+        contig = 1;
+        blocks = (total + 511) / 512;
+    } else {   // grid stride = a multiple of the chunks per voxel row (cpr <= 256: one block's 256 threads times need)
         int gq = cpr, g256 = 256;
         while (g256) { const int t = gq % g256; gq = g256; g256 = t; }     // gcd(cpr, 256)
         const int need = cpr / gq;
@@ -388,11 +394,11 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
     if (add)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)blocks, n), dim3(256), 5 * c * sizeof(float), st,
                            (const bf16_t*)g_buf, (const bf16_t*)x, sums, gamma, s12, (const bf16_t*)add, (bf16_t*)dx, c, vox,
-                           groups, eps);
+                           groups, eps, contig);
     else
         hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3((unsigned)blocks, n), dim3(256), 5 * c * sizeof(float), st,
                            (const bf16_t*)g_buf, (const bf16_t*)x, sums, gamma, s12, (const bf16_t*)add, (bf16_t*)dx, c, vox,
-                           groups, eps);
+                           groups, eps, contig);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }
@@ -495,23 +501,34 @@ extern "C" int ctsi_channel_sum(const void* x, long long rows, int c, int c_stri
 }
 
 // ==== small elementwise helpers ======================================================================================
+// (one contiguous batch of 4 x 256 16-byte chunks per block, blocks in address order: see ctsi_gn_apply)
 __global__ void __launch_bounds__(256) add_bf16_kernel(bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long long chunks) {
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < chunks; e += (long long)gridDim.x * 256) {
-        float fa[8], fb[8];
-        t_unpack8(*reinterpret_cast<const uint4*>(a + e * 8), fa);
-        t_unpack8(*reinterpret_cast<const uint4*>(b + e * 8), fb);
+    const long long e0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+    uint4 ra[4], rb[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) fa[k] += fb[k];
-        *reinterpret_cast<uint4*>(a + e * 8) = t_pack8(fa);
-    }
+    for (int u = 0; u < 4; ++u)
+        if (e0 + u * 256 < chunks) {
+            ra[u] = *reinterpret_cast<const uint4*>(a + (e0 + u * 256) * 8);
+            rb[u] = *reinterpret_cast<const uint4*>(b + (e0 + u * 256) * 8);
+        }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (e0 + u * 256 < chunks) {
+            float fa[8], fb[8];
+            t_unpack8(ra[u], fa);
+            t_unpack8(rb[u], fb);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fa[k] += fb[k];
+            *reinterpret_cast<uint4*>(a + (e0 + u * 256) * 8) = t_pack8(fa);
+        }
 }
 extern "C" int ctsi_add_bf16(void* a, const void* b, long long count, void* stream) {
     CTSI_CHECK_ARG(a && b && count >= 0 && count % 8 == 0, "ctsi_add_bf16: count must be a multiple of 8");
     if (count == 0) return CTSI_OK;
-    long long blocks = (count / 8 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    const long long chunks = count / 8;
+    const long long blocks = (chunks + 1023) / 1024;
     hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)a,
-                       (const bf16_t*)b, count / 8);
+                       (const bf16_t*)b, chunks);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

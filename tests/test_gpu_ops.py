@@ -450,6 +450,38 @@ def test_groupnorm_statistics_are_bit_stable(G):
         assert torch.equal(s_, runs[0])
 
 
+def test_groupnorm_statistics_split_finalize(G):
+    """Tensors with thousands of tiles per (sample, group) take the split form of ctsi_gn_finalize (S slices, the block that draws
+    the last ticket adds the S partial pairs in slice order): bit-identical from run to run, and equal to the fp64 sums of the
+    bf16 tensor."""
+    E, ctx = G.E, G.ctx()
+    n, c, d, h, w, groups = 1, 64, 16, 256, 512, 4        # 4096 tiles x 4 float4 items per group = 16384 -> 2 slices
+    with ctx.scope():
+        prog = E.Program(ctx)
+        a = prog.act(n, c, d, h, w)
+        gen = torch.Generator(device=ctx.device).manual_seed(5)
+        a.t.copy_((torch.randn(a.t.shape, generator=gen, device=ctx.device) * 1.5 + 0.25).to(a.t.dtype))
+        prog.zero_gn_op()
+        st = prog.gn_colsum(a)
+        slot = prog.gn_finalize(a, groups, st)
+        prog.finalize_layout()
+        runs = []
+        for _ in range(3):
+            prog.run()
+            torch.cuda.synchronize()
+            runs.append(prog._gn_sums[slot:slot + n * groups * 2].clone())
+        xf = a.t.view(torch.bfloat16).reshape(-1, c).double()
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
+    got = runs[0].reshape(n * groups, 2).cpu()
+    cpg = c // groups
+    for g in range(groups):
+        blk = xf[:, g * cpg:(g + 1) * cpg]
+        s1, s2 = float(blk.sum()), float((blk * blk).sum())
+        assert abs(float(got[g, 0]) - s1) <= 2e-5 * max(1.0, abs(s1)) + 64.0      # fp32 tile partials, fp64 above them
+        assert abs(float(got[g, 1]) - s2) <= 2e-5 * s2
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 3, 5, 7), (1, 192, 2, 3, 5), (1, 128, 6, 24, 32)],
                          ids=["c64-small", "c192-lds-coefficients", "c128-grid-stride"])
 def test_groupnorm_apply_variants(G, shape):

@@ -96,11 +96,22 @@ extern "C" int ctsi_gn_colsum(const void* x, float* colsum, int n, int c, int d,
 // tile partials in a fixed order, the block combines them with a fixed-shape tree, and the result is WRITTEN (not
 // accumulated) -- the statistics are bit-identical from run to run by construction (no atomics, no dependence on block
 // scheduling), and the sums buffer needs no zeroing.
+// Split form (gridDim.z = S > 1: tensors with tens of thousands of tiles -- the VAE at full resolution: 24576 tiles, 3 MB of
+// partials per group, 71 us per launch when ONE block read them): slice s of a (sample, group) sums items
+// [s * per, (s + 1) * per) the same way, parks its pair in a scratch row (agent-scope stores) and takes a ticket; the block that
+// draws the last ticket adds the S pairs IN SLICE ORDER and writes the result: still no dependence on block scheduling.
+#define GN_FIN_ROWS 2048
+#define GN_FIN_SMAX 16
+#define GN_FIN_SLOTS 4
+__device__ double g_fin_part[GN_FIN_SLOTS][GN_FIN_ROWS][GN_FIN_SMAX][2];
+__device__ unsigned int g_fin_ticket[GN_FIN_SLOTS][GN_FIN_ROWS];
+
 __global__ void __launch_bounds__(1024)
 gn_finalize_kernel(const float* __restrict__ colsum, double* __restrict__ sums, int n_total, int c_pad,
-                   int groups, int cpg, int tps, int nclass, int accumulate) {
+                   int groups, int cpg, int tps, int nclass, int accumulate, int slot) {
     const int g = blockIdx.x, nb = blockIdx.y;
     const int tid = threadIdx.x;
+    const int S = gridDim.z, sl = blockIdx.z;
     const long long slab = (long long)nclass * n_total * tps * c_pad;
     const int items = tps * cpg;
     double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -108,12 +119,15 @@ gn_finalize_kernel(const float* __restrict__ colsum, double* __restrict__ sums, 
         // 16-byte loads, 8 of them in flight per thread and statistic: a group's cpg channels of one tile row are contiguous.
         // Large tensors (the VAE decoder at full resolution: 24576 tiles per sample) are latency-, not bandwidth-bound here:
         // the scalar form below took 30-140 us per launch on them (15 launches per decode), this one a few us.
-        const int q4 = cpg >> 2, items4 = tps * q4;
+        const int q4 = cpg >> 2, items4_all = tps * q4;
+        const int per = S > 1 ? ((items4_all + S - 1) / S + 1023) / 1024 * 1024 : items4_all;   // (whole thread rounds per slice)
+        const int it0 = sl * per;
+        const int items4 = it0 + per < items4_all ? it0 + per : items4_all;
         const float4* cs1 = reinterpret_cast<const float4*>(colsum);
         const float4* cs2 = reinterpret_cast<const float4*>(colsum + slab);
         for (int cls = 0; cls < nclass; ++cls) {
             const long long tbase = ((long long)cls * n_total + nb) * tps;
-            int it = tid;
+            int it = it0 + tid;
             for (; it + 7 * 1024 < items4; it += 8 * 1024) {
                 float4 v1[8], v2[8];
 #pragma unroll
@@ -182,9 +196,31 @@ gn_finalize_kernel(const float* __restrict__ colsum, double* __restrict__ sums, 
         }
     }
     if (tid == 0) {
-        double* o = sums + ((long long)nb * groups + g) * 2;
-        o[0] = (accumulate ? o[0] : 0.0) + s1[0];
-        o[1] = (accumulate ? o[1] : 0.0) + s2[0];
+        double t1 = s1[0], t2 = s2[0];
+        bool last = true;
+        if (S > 1) {
+            const int row = nb * groups + g;
+            double* part = &g_fin_part[slot][row][0][0];
+            __hip_atomic_store(part + 2 * sl + 0, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part + 2 * sl + 1, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tk = __hip_atomic_fetch_add(&g_fin_ticket[slot][row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = tk == (unsigned)(S - 1);
+            if (last) {
+                __hip_atomic_store(&g_fin_ticket[slot][row], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                t1 = 0.0;
+                t2 = 0.0;
+                for (int k = 0; k < S; ++k) {
+                    t1 += __hip_atomic_load(part + 2 * k + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    t2 += __hip_atomic_load(part + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (last) {
+            double* o = sums + ((long long)nb * groups + g) * 2;
+            o[0] = (accumulate ? o[0] : 0.0) + t1;
+            o[1] = (accumulate ? o[1] : 0.0) + t2;
+        }
     }
 }
 
@@ -193,8 +229,21 @@ extern "C" int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c,
     CTSI_CHECK_ARG(colsum && sums, "ctsi_gn_finalize: null argument");
     CTSI_CHECK_ARG(groups > 0 && c % groups == 0, "ctsi_gn_finalize: c=%d not divisible by groups=%d", c, groups);
     const int cpg = c / groups;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n), dim3(1024), 0, (hipStream_t)stream, colsum, sums, n, c_pad,
-                       groups, cpg, tiles_per_sample, nclass, accumulate);
+    // slices: one per 8192 16-byte items of a (sample, group) (the vector path only), at most 16; scratch rows rotate over 4
+    // slots per call so that consecutive launches never share one
+    int S = 1;
+    static int call_no = 0;
+    if ((cpg & 3) == 0 && (c_pad & 3) == 0 && nclass == 1 && (long long)n * groups <= GN_FIN_ROWS) {
+        const long long items4 = (long long)tiles_per_sample * (cpg >> 2);
+        S = (int)(items4 / 8192);
+        if (S > GN_FIN_SMAX) S = GN_FIN_SMAX;
+        if (S < 1) S = 1;
+        static const char* fs = getenv("CTSI_GN_FIN_SPLIT");
+        if (fs && atoi(fs) == 0) S = 1;
+    }
+    const int slot = S > 1 ? (call_no++ & (GN_FIN_SLOTS - 1)) : 0;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n, S), dim3(1024), 0, (hipStream_t)stream, colsum, sums, n, c_pad,
+                       groups, cpg, tiles_per_sample, nclass, accumulate, slot);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }

@@ -284,7 +284,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         const int cc = q / TAPS, t = q - cc * TAPS;
         int kd, kh, kw;                                      // halo coordinates of the tap (0..2 each)
         if (TR) {
-            kd = 2 - (t >> 2);
+            kd = t >> 2;                                     // (entry t holds kernel tap k_d = 2 - (t >> 2): halo slices ascending)
             kh = ((t >> 1) & 1) ? (py ? 2 : 0) : 1;
             kw = (t & 1) ? (px ? 2 : 0) : 1;
         } else if (DS) {                                     // class of the virtual chunk: (cbase + cc) & 3 (cbase % 4 == 0)
@@ -358,11 +358,11 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         s_rowoff[tid] = off;
     }
 
-    // 3x3x3 and Downsample forms (taps ordered k_d first): step 0 and the fragment loads it runs ahead read taps with k_d = 0, i.e. halo depth slices 0 .. TD - 1 only;
+    // Every form orders its entries by halo depth slice: step 0 and the fragment loads it runs ahead read slice offsets 0 only, i.e. halo depth slices 0 .. TD - 1;
     // the pieces that hold slices TD, TD + 1 (the youngest halo pieces of a wave, issued before the weights of steps 1-2) may
     // stay in flight as well: B_0 waits for everything but the weights of step 2, and slice TD is first read behind B_1.
     int n_late = 0;
-    if constexpr (!TR) {
+    {
         constexpr int NEED = (Cfg::TD * HH * HW + 31) / 32;
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) n_late += (wave + NWAVE * i >= NEED && wave + NWAVE * i < HALO_INSTR) ? 1 : 0;
@@ -636,7 +636,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
 
 // ---- weight packing: fp32 (cout, cin, 3,3,3) -> bf16 [entry q = chunk16 * 27 + tap][cout_pad][16], zero entries up to whole steps;
 //      ConvTranspose3d (cin, cout, 3,4,4) -> [class][entry q = chunk16 * 12 + t][cout_pad][16], t = (a * 2 + b) * 2 + c with
-//      kernel taps k_d = a, k_h = (py ? {2, 0} : {1, 3})[b], k_w likewise (the tap order conv3_halo_k32_kernel<TR> walks)
+//      kernel taps k_d = 2 - a (halo slices ascending), k_h = (py ? {2, 0} : {1, 3})[b], k_w likewise (the tap order conv3_halo_k32_kernel<TR> walks)
 __global__ void conv3_halo_k32_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int CoutPad,
                                            int CinW, int nchunks, long long per_class, int form) {
     // form 0: 3x3x3; 1: ConvTranspose3d (3,4,4)/(1,2,2) (4 class images); 2: Conv3d (3,4,4)/(1,2,2) (nchunks = 4 virtual chunks
@@ -664,7 +664,7 @@ __global__ void conv3_halo_k32_pack_kernel(const float* __restrict__ w, bf16_t* 
                     v = w[((long long)co * CinW + ci) * 48 + (a * 4 + 2 * b + 1 - py) * 4 + 2 * c + 1 - px];
                 } else if (transposed) {
                     const int py = cls >> 1, px = cls & 1;
-                    const int a = t >> 2, b = (t >> 1) & 1, c = t & 1;
+                    const int a = 2 - (t >> 2), b = (t >> 1) & 1, c = t & 1;   // i_d = o_d + 1 - k_d: k_d descending = halo slices ascending
                     const int ky = py ? (b ? 0 : 2) : (b ? 3 : 1), kx = px ? (c ? 0 : 2) : (c ? 3 : 1);
                     v = w[((long long)ci * Cout + co) * 48 + (a * 4 + ky) * 4 + kx];
                 } else {

@@ -117,6 +117,10 @@ def shard_parity_check(P, E, model, ctx, dev, rank, world, dist, tol=3e-2):
         eps_ref = ref.eps_ncdhw()
         del ref
     for name in ("dist", "rccl"):
+        # The verdict is COLLECTIVE: a rank whose transport throws must not skip the all-reduce its peers are blocked in (and
+        # must not move on to the next transport's collectives on its own), so the failure is folded into the error value
+        # (1e9) and every rank makes the same all_reduce(MAX) on torch.distributed's own group, outside the try.
+        err, info, failure = torch.full((1,), 1e9, dtype=torch.float64), {}, None
         try:
             comm = P.DistComm() if name == "dist" else P.RcclComm.from_process_group()
             spec = P.ShardSpec(rank, world, comm, d)
@@ -126,16 +130,25 @@ def shard_parity_check(P, E, model, ctx, dev, rank, world, dist, tol=3e-2):
                 pr.set_schedule([500])
                 pr.run()
                 full = comm.gather_depth(rank, pr.eps_ncdhw(), counts=spec.depth_counts)
-                split = any(m[0] == "halo.exchange.async" for m in pr.op_meta)
+                info = {"depth": d, "slabs": spec.depth_counts,
+                        "overlap_split": any(m[0] == "halo.exchange.async" for m in pr.op_meta)}
                 del pr
             torch.cuda.synchronize()
-            err = ((full.double() - eps_ref.double()).norm() / eps_ref.double().norm()).reshape(1)
-            err = torch.nan_to_num(err, nan=1e9).to(dev)
+            err = ((full.double() - eps_ref.double()).norm() / eps_ref.double().norm()).reshape(1).cpu()
+            err = torch.nan_to_num(err, nan=1e9)
+        except Exception as exc:   # reported, not fatal -- as long as torch.distributed itself still works (below)
+            failure = f"{type(exc).__name__}: {exc}"[:300]
+        err = err.to(dev)
+        try:
             dist.all_reduce(err, op=dist.ReduceOp.MAX)
-            res[name] = {"rel_l2_vs_unsharded_max_over_ranks": float(err.item()), "ok": bool(err.item() < tol),
-                         "depth": d, "slabs": spec.depth_counts, "overlap_split": split}
-        except Exception as exc:   # a transport that cannot even start is reported, not fatal: the other one is timed
-            res[name] = {"ok": False, "error": f"{type(exc).__name__}: {exc}"[:300]}
+        except Exception as exc:   # the process group itself is broken: nothing sensible can follow
+            raise SystemExit(f"rank {rank}: torch.distributed all_reduce failed after the '{name}' transport check: {exc}")
+        worst = float(err.item())
+        res[name] = {"rel_l2_vs_unsharded_max_over_ranks": worst, "ok": bool(worst < tol), **info}
+        if failure is not None:
+            res[name]["error"] = failure
+        elif worst >= 1e9:
+            res[name]["error"] = "another rank failed (see its log)"
     return res
 
 

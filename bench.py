@@ -13,9 +13,13 @@ Extra objects on the same line:
                  halo-tile conv): algorithmic FLOPs of its launches in one U-Net evaluation / their
                  summed duration, measured with HIP events on the engine stream around every launch
                  (eager pass, not the graph).  `conv_family` aggregates every MFMA conv launch.
-  cpu_baseline — the CPU oracle (fp32 torch ops, 16 host threads) timed on a bounded sample of the same workload:
-                 ONE U-Net evaluation on the benchmarked latent (1,8,48,128,128) = one step; rank 0, N == 1 only.
-  volume_wall_s — wall-clock of the whole 8->48 @512^2 generate() (encode + 51 steps + decode).
+  cpu_baseline — the CPU oracle (fp32 torch ops, every core the process may run on; `host_cores` = os.cpu_count()) timed on a
+                 bounded sample of the same workload: ONE U-Net evaluation on the benchmarked latent (1,8,48,128,128) = one
+                 step; rank 0, N == 1 only.  --cpu-config1 adds BASELINE config 1 phase by phase (minutes).
+  volume_wall_s — wall-clock of the whole 8->48 @512^2 generate() (encode + 51 steps + decode), warm;
+                 volume_wall_first_call_s = the cold first call (plans, 0.53 GB weight pack, graph capture).
+  config.captured_vs_eager_rel_l2 — the timed hipGraph step replayed once more against the same step launched eagerly from
+                 the same state (must be 0); eps_checksum_per_rank: one checksum of that noise prediction per rank.
 """
 import argparse
 import importlib
@@ -58,7 +62,13 @@ def parse():
     ap.add_argument("--no-volume", action="store_true", help="skip the end-to-end generate() timing")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU oracle leg")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads for the CPU oracle leg (0 = every core this process may run on)")
+    ap.add_argument("--cpu-config1", action="store_true",
+                    help="also time BASELINE config 1 phase by phase on the host cores (encode, one U-Net evaluation, DDIM-10, "
+                         "decode at 192x192: minutes of CPU work, so not part of the default run; BASELINE.md section 4)")
+    ap.add_argument("--sampler", choices=["ddim", "ddpm"], default="ddim",
+                    help="sampler of the end-to-end volume_wall_s leg (ddpm = all 1000 ancestral steps, models/diffusion.py:340-367)")
     ap.add_argument("--model", choices=["effective", "legacy163"], default="effective",
                     help="effective: what the production YAML builds (264.66 M U-Net, the headline); legacy163: the flat "
                          "163.4 M-param variant (latent 4, 3 levels) - secondary figure, skips the CPU leg")
@@ -72,12 +82,25 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(threads, latent_hw, depth):
+def _host_cores():
+    """(cores this process may run on, cores of the host): the GPU boxes hand a container a CPU share, so the affinity mask
+    -- not os.cpu_count() -- is what 'all cores' means here."""
+    total = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = total
+    return max(1, min(avail, total)), total
+
+
+def cpu_baseline(threads, latent_hw, depth, config1=False):
     """Oracle U-Net evaluation on the host cores: ONE step's U-Net evaluation of the benchmarked workload itself
-    (latent (1,8,depth,hw,hw); 31.4 TFLOP at 512x512 = roughly 15-20 s on 16 threads)."""
+    (latent (1,8,depth,hw,hw); 31.4 TFLOP at 512x512 = roughly 15-25 s).  `cores` = threads used = every core this process
+    may run on unless --cpu-threads says otherwise; `host_cores` = os.cpu_count().  config1: BASELINE config 1 phase by phase."""
     from oracle import ref_ops as R
     pkg = importlib.import_module("video-to-video-diffusion_amd")
-    cores = max(1, min(threads, os.cpu_count() or 1))
+    avail, total = _host_cores()
+    cores = avail if threads <= 0 else max(1, min(threads, total))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     un = pkg.UNet3D(latent_dim=8).eval()
@@ -93,9 +116,39 @@ def cpu_baseline(threads, latent_hw, depth):
         R.unet_forward(sd, cfg, x, t, c)
         dt = time.time() - t0
     flops = 31408.6e9 * (depth * latent_hw * latent_hw) / (48 * 128 * 128)
-    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 U-Net evaluation (fp32 torch CPU oracle) on the benchmarked latent {list(shape)}: "
-                      f"{dt:.2f} s, {flops / dt / 1e9:.0f} GFLOP/s (the DDIM update itself is negligible)"}
+    res = {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "host_cores": total, "cores_available": avail, "kind": "port",
+           "sample": f"1 U-Net evaluation (fp32 torch CPU oracle, {cores} threads) on the benchmarked latent {list(shape)}: "
+                     f"{dt:.2f} s, {flops / dt / 1e9:.0f} GFLOP/s (the DDIM update itself is negligible)"}
+    if config1:
+        # config 1 (192x192 patch, 8 -> 48 slices, DDIM-10) phase by phase, seeds as in the survey
+        torch.manual_seed(0)
+        model = pkg.VideoToVideoDiffusion(EFFECTIVE_CFG).eval()
+        msd = {k: v.detach() for k, v in model.state_dict().items()}
+        mcfg = dict(cfg, scaling_factor=1.0)
+        torch.manual_seed(1)
+        v_in = torch.rand(1, 1, 8, 192, 192) * 2 - 1
+        ph = {}
+        with torch.no_grad():
+            t0 = time.time()
+            z_in = R.vae_encode(msd, v_in, 1.0, "vae.")
+            ph["vae_encode_s"] = time.time() - t0
+            z_c = R.trilinear_depth(z_in, 48)
+            torch.manual_seed(2)
+            zt = torch.randn(z_c.shape)
+            t0 = time.time()
+            R.unet_forward(msd, mcfg, zt, torch.tensor([500]), z_c, "unet.")
+            ph["unet_eval_s"] = time.time() - t0
+            bufs = {k[len("diffusion."):]: v for k, v in msd.items() if k.startswith("diffusion.")}
+            t0 = time.time()
+            z0 = R.ddim_sample(lambda z, tt, cc: R.unet_forward(msd, mcfg, z, tt, cc, "unet."), bufs, tuple(z_c.shape), z_c, 10)
+            ph["ddim10_11_evals_s"] = time.time() - t0
+            t0 = time.time()
+            R.vae_decode(msd, z0, 1.0, "vae.")
+            ph["vae_decode_s"] = time.time() - t0
+        ph["end_to_end_s"] = ph["vae_encode_s"] + ph["ddim10_11_evals_s"] + ph["vae_decode_s"]
+        ph["ddim_steps_per_s"] = 11.0 / ph["ddim10_11_evals_s"]
+        res["config1_192_phases"] = ph
+    return res
 
 
 def shard_parity_check(P, E, model, ctx, dev, rank, world, dist, tol=3e-2):
@@ -509,21 +562,48 @@ def main():
         dt = float(tmax.item())
     with ctx.scope():
         finite = bool(torch.isfinite(prog.z_ncdhw()).all().item())
+        # What the timed graph computes, checked beyond "finite": one more replay of the captured step against the same
+        # step launched eagerly from the same state (z, conditioning, step counter): identical kernels in identical order, so
+        # the noise predictions must agree to the last bit.
+        z_keep, xin_keep, sp_keep = prog.z.clone(), prog.xin.t.clone(), prog.step_ptr.clone()
+        prog.launch()
+        eps_graph = prog.eps.clone()
+        prog.z.copy_(z_keep)
+        prog.xin.t.copy_(xin_keep)
+        prog.step_ptr.copy_(sp_keep)
+        prog.run()
+        eps_eager = prog.eps.clone()
+        cap_vs_eager = float(((eps_graph.double() - eps_eager.double()).norm() / eps_eager.double().norm().clamp_min(1e-30)).item())
+        finite = finite and bool(torch.isfinite(eps_graph).all().item()) and float(eps_graph.abs().sum().item()) > 0.0
+        checksum = eps_graph.double().sum().reshape(1)
+    rank_checksums = None
+    if dist is not None:      # data parallel, N > 1: one checksum of the captured step's noise prediction per rank
+        allc = [torch.zeros_like(checksum) for _ in range(world)]
+        dist.all_gather(allc, checksum)
+        rank_checksums = [float(c.item()) for c in allc]
+        fin = torch.tensor([1.0 if (finite and cap_vs_eager == 0.0) else 0.0], device=dev)
+        dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+        finite = bool(fin.item() > 0.5)
+    else:
+        rank_checksums = [float(checksum.item())]
 
     unet_flops = prog.flops
     del prog
     model.unet.__dict__.pop("_ctsi_programs", None)
     torch.cuda.empty_cache()
 
-    volume_wall, vae_legs = None, None
+    volume_wall, volume_wall_first, vae_legs = None, None, None
     if not args.no_volume and world == 1:
         v_in = (torch.rand(n, 1, args.depth_in, args.hw, args.hw, generator=gen) * 2 - 1).to(dev)
-        for rep in range(2):  # first pass builds/captures programs, second is the measurement
+        model.invalidate_engine_cache()      # the first call below is a COLD one: plans, weight packing (0.53 GB), graph capture
+        for rep in range(2):  # first pass builds/captures programs (reported as volume_wall_first_call_s), second is the measurement
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            v_out = model.generate(v_in, 'ddim', num_inference_steps=args.ddim_steps, target_depth=args.depth_out)
+            v_out = model.generate(v_in, args.sampler, num_inference_steps=args.ddim_steps, target_depth=args.depth_out)
             torch.cuda.synchronize()
             volume_wall = time.perf_counter() - t1
+            if rep == 0:
+                volume_wall_first = volume_wall
         finite = finite and bool(torch.isfinite(v_out).all().item()) and tuple(v_out.shape) == (n, 1, args.depth_out,
                                                                                                  args.hw, args.hw)
         # the two frozen-VAE legs of the volume on their own (programs are cached by the generate() calls above)
@@ -554,12 +634,14 @@ def main():
                                       else "legacy 163.4M U-Net (128x(1,2,4), latent 4)")
                                    + ", one volume per GPU, hipGraph-captured step",
                        "volumes_per_gpu": n, "parallelism": f"dp{world}", "finite_outputs": finite,
+                       "captured_vs_eager_rel_l2": cap_vs_eager, "eps_checksum_per_rank": rank_checksums,
                        "unet_tflop_per_step": unet_flops / 1e12,
                        "unet_tflops_achieved_per_gpu": unet_flops * args.steps / dt / 1e12},
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu or world > 1) else cpu_baseline(args.cpu_threads, args.hw // 4,
-                                                                                  args.depth_out),
-            "volume_wall_s": volume_wall,
+                                                                                  args.depth_out, args.cpu_config1),
+            "volume_wall_s": volume_wall, "volume_wall_first_call_s": volume_wall_first,
+            "volume_sampler": (f"ddim-{args.ddim_steps}" if args.sampler == "ddim" else "ddpm-1000"),
             "vae": vae_legs if (not args.no_volume and world == 1) else None,
         }
         print(json.dumps(res))

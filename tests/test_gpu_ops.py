@@ -323,6 +323,22 @@ def test_split_k_conv_is_bit_stable_and_matches(G, monkeypatch):
     sums = outs[0][1].reshape(n, 8, 2).cpu()
     assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
     assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
+    # A hand-off whose consumer gave up leaves the tile's ticket / flag words set (ticket 2, flag 1).  The NEXT launch must not
+    # pass as healthy: it raises the sticky device error again, check_device_errors() reports it and re-zeroes the workspace of
+    # every live program, after which the layer is exact again.
+    E.check_device_errors(c)                                   # clean so far
+    with c.scope():
+        ws = prog._sk_workspaces[0]
+        ws[:8].view(torch.int32).copy_(torch.tensor([2, 1], dtype=torch.int32))
+        prog.run()
+    with pytest.raises(E.CtsiError, match="device-side error"):
+        E.check_device_errors(c)
+    assert int(ws[:8].view(torch.int32).abs().sum()) == 0      # re-zeroed by the check
+    with c.scope():
+        prog.run()
+        again = G.from_act(prog, y).clone()
+    E.check_device_errors(c)
+    assert torch.equal(again, outs[0][0])
 
 
 CONVT_CASES = [
@@ -421,6 +437,48 @@ def test_conv3_head_kernel(G, monkeypatch, name, cin, cout, dims, f32, act):
     monkeypatch.setenv("CTSI_CONV_NO_HEAD3", "1")
     y2, _ = G.run_conv(x, None, wt, b, f32=f32, act=act)
     assert float((y - y2).abs().max()) <= (1e-4 if f32 else 2.0 ** -7) * float(ref.abs().max())
+
+
+HEAD2_CASES = [
+    # name, cout, (n,d,h,w), f32, act
+    ("vae_head_ragged", 1, (1, 3, 6, 20), True, 1),
+    ("vae_head_tiles_batch2_segments", 1, (2, 20, 40, 70), True, 1),     # 3 x 3 plane tiles, two depth segments of 10 planes
+    ("unet_head_f32", 8, (1, 4, 8, 32), True, 0),
+    ("unet_head_tiles_batch2_segments", 8, (2, 17, 21, 37), True, 0),    # 3 x 3 plane tiles, segments of 9 and 8 planes
+    ("unet_head_bf16_out", 8, (1, 5, 9, 18), False, 0),
+]
+
+
+@pytest.mark.parametrize("name,cout,dims,f32,act", HEAD2_CASES, ids=[c[0] for c in HEAD2_CASES])
+def test_conv3_head2_kernel(G, monkeypatch, name, cout, dims, f32, act):
+    """conv3_head2.hip (the in-plane taps as the GEMM's N dimension, depth taps summed in three rotating accumulator sets
+    while the block marches along depth): against F.conv3d, against conv3_head_kernel on the same problem, and -- every tap
+    in its place -- a one-hot weight per tap must reproduce the shifted input bit for bit."""
+    n, d, h, w = dims
+    cin = 128
+    x = bf16_round(formula_input((n, cin, d, h, w), 41))
+    wt = bf16_round(_w((cout, cin, 3, 3, 3), 42))
+    b = formula_input((cout,), 43) * 0.1
+    ref = F.conv3d(x, wt, b, padding=1)
+    if act:
+        ref = torch.tanh(ref)
+    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
+    y, _ = G.run_conv(x, None, wt, b, f32=f32, act=act)
+    assert tuple(y.shape) == tuple(ref.shape)
+    e = rel_l2(y, ref)
+    assert e < (2e-4 if f32 else CONV_TOL), (name, e)
+    monkeypatch.setenv("CTSI_CONV_NO_HEAD2", "1")
+    y1, _ = G.run_conv(x, None, wt, b, f32=f32, act=act)
+    assert float((y - y1).abs().max()) <= (1e-4 if f32 else 2.0 ** -7) * float(ref.abs().max())
+    monkeypatch.delenv("CTSI_CONV_NO_HEAD2")
+    if f32 and n == 1:
+        for tap in range(27):          # out[co] = x[channel 5 + co] shifted by the tap: exact in fp32
+            w1 = torch.zeros(cout, cin, 27)
+            for co in range(cout):
+                w1[co, 5 + co, tap] = 1.0
+            w1 = w1.reshape(cout, cin, 3, 3, 3)
+            y1, _ = G.run_conv(x, None, w1, None, f32=True)
+            assert torch.equal(y1, F.conv3d(x, w1, None, padding=1)), (name, tap)
 
 
 def test_conv_linearity_and_zero_padding_property(G):

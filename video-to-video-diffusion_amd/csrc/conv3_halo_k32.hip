@@ -483,7 +483,19 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         constexpr int NREG = MA * NJ * 4;
         float* wsl = p.sk_ws + (size_t)tile * NREG * NTH + tid;
         int* s_role = reinterpret_cast<int*>(s_cs);          // (s_cs is first written after the barriers below)
-        if (tid == 0) *s_role = __hip_atomic_fetch_add(p.sk_sync + 2 * tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            const int tk = __hip_atomic_fetch_add(p.sk_sync + 2 * tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // A ticket >= 2 means an EARLIER launch left this tile's hand-off words set (its consumer's wait expired, see below):
+            // nothing computed on them can be trusted, so this launch raises the sticky error as well -- the condition stays
+            // visible to every ctsi_device_error_status() until the host has re-zeroed the workspace (engine.check_device_errors
+            // does so for every live program) -- and the two blocks still take complementary roles by parity: no block waits
+            // on a partner that also waits.
+            if (tk >= 2) {
+                atomicAdd(&g_hk_device_error[0], 1u);
+                g_hk_device_error[1] = (unsigned)tile;
+            }
+            *s_role = tk & 1;
+        }
         __syncthreads();
         const int role = *s_role;
         __syncthreads();

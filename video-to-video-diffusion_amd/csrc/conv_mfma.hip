@@ -743,6 +743,7 @@ struct ctsi_conv_plan {
     int m512_w16;   // halo3 == 7 only: tile of the k32 kernel: 0 = 4x4x32, 2 = 4x8x16, 3 = 3x4x32, 5 = 3x8x16 (384 voxels)
     int gsplit;     // gather kernel (halo3 == 0): S-way split-K for launches of a few dozen blocks with a deep K loop (needs a workspace)
     int ds;         // halo3 == 7: the strided (3,4,4)/(1,2,2) Downsample form of the k32 kernel (conv3_halo_k32.hip, DS)
+    int head2;      // halo3 == 6: conv3_head2_kernel (taps as the GEMM's N dimension) serves the launches that ask for no column sums
     int ksplit;     // halo3 == 7, tile 5: 2 = two blocks per (tile, n-tile), each half of the input-channel chunks (needs a workspace)
     int halo3;  // 3x3x3 halo-tile kernels: 2 = conv3_halo32_kernel (conv3_halo.hip: 4x2x32 / 4x4x16 / 3x4x16 tiles), 6 = few-cout
                 // heads (conv3_head.hip), 7 = conv3_halo_k32_kernel (conv3_halo_k32.hip: 512- / 384-voxel tiles, ConvTranspose).
@@ -1141,6 +1142,7 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             p->halo3 = 6;
             p->BM = 128;
             p->BN = 16;
+            p->head2 = ctsi_conv3_head2_supported(p->Cin, d.cout) && p->CinW == p->Cin && !getenv("CTSI_CONV_NO_HEAD2");
         }
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
@@ -1212,6 +1214,11 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
 
 extern "C" void ctsi_conv_plan_destroy(ctsi_conv_plan* plan) { free(plan); }
 
+// few-cout heads (halo3 == 6): the packed buffer holds conv3_head_kernel's image, padded to 256 B, then conv3_head2_kernel's
+static size_t head1_bytes(const ctsi_conv_plan* p) {
+    return ((size_t)p->Cin * 27 * (p->d.cout <= 8 ? 8 : 16) * 2 + 1024 + 255) / 256 * 256;
+}
+
 extern "C" int ctsi_conv_plan_out_dims(const ctsi_conv_plan* p, int* d, int* h, int* w) {
     CTSI_CHECK_ARG(p, "ctsi_conv_plan_out_dims: null plan");
     if (d) *d = p->Do;
@@ -1221,8 +1228,8 @@ extern "C" int ctsi_conv_plan_out_dims(const ctsi_conv_plan* p, int* d, int* h, 
 }
 extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
     if (!p) return 0;
-    if (p->halo3 == 6)   // head kernel: 8 weight rows when cout <= 8; + 1 KB: its last DMA piece is read whole
-        return (size_t)p->Cin * 27 * (p->d.cout <= 8 ? 8 : 16) * 2 + 1024;
+    if (p->halo3 == 6)   // head kernels: conv3_head's image (8 weight rows when cout <= 8; + 1 KB: its last DMA piece is read whole),
+        return head1_bytes(p) + (ctsi_conv3_head2_supported(p->Cin, p->d.cout) ? ctsi_conv3_head2_weight_bytes(p->d.cout) : 0);   // then conv3_head2's
     if (p->halo3 == 7) return ctsi_conv3_halo_k32_weight_bytes(p->Cin, p->CoutPad, p->BN, p->ds ? 2 : p->d.transposed);   // entries padded to whole steps
     if (p->halo3) return (size_t)p->Cin * 27 * p->CoutPad * 2;   // [chunk][27][cout_pad][32 | 16 ch] bf16
     return (size_t)p->nclass * p->CoutPad * p->Ktot * 2;
@@ -1262,7 +1269,11 @@ extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float*
     if (p->halo3 == 7)
         return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, p->BN, p->ds ? 2 : p->d.transposed, stream);
     if (p->halo3 == 6) {
-        hipMemsetAsync((char*)packed + ctsi_conv_plan_weight_bytes(p) - 1024, 0, 1024, (hipStream_t)stream);
+        hipMemsetAsync((char*)packed + head1_bytes(p) - 1280, 0, 1280, (hipStream_t)stream);
+        if (ctsi_conv3_head2_supported(p->Cin, p->d.cout)) {
+            const int rc = ctsi_conv3_head2_pack(w, (char*)packed + head1_bytes(p), p->d.cout, p->Cin, p->CinW, stream);
+            if (rc != CTSI_OK) return rc;
+        }
         return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->d.cout <= 8 ? 8 : 16, p->Cin, p->CinW, stream);
     }
     if (p->halo3) return ctsi_conv3_halo_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, stream);
@@ -1387,8 +1398,14 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
         }
-        if (p->halo3 == 6)
+        if (p->halo3 == 6) {
+            // second form (taps as the GEMM's N dimension, input read once straight into the MFMA layout: conv3_head2.hip) for the
+            // layers it covers; conv3_head_kernel keeps the others and the GroupNorm column sums.  CTSI_CONV_NO_HEAD2: A/B timing
+            if (p->head2 && o->colsum == nullptr)
+                return ctsi_conv3_head2_launch(&h, p->d.n, (const char*)packed_w + head1_bytes(p), o->mode, o->act, o->sn, o->sc, o->sd,
+                                               o->sh, o->sw, stream);
             return ctsi_conv3_head_launch(&h, p->d.cout <= 8 ? 8 : 16, o->mode, o->act, o->sn, o->sc, o->sd, o->sh, o->sw, stream);
+        }
         h.tr = p->d.transposed;
         if (p->halo3 == 7 && p->ksplit == 2) {
             CTSI_CHECK_ARG(o->workspace, "ctsi_conv_fwd: this plan needs ctsi_conv_out.workspace (ctsi_conv_plan_workspace_bytes)");

@@ -145,6 +145,11 @@ extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int 
 extern "C" int ctsi_conv3_halo_launch(const Conv3HaloParams* hp, int wide, void* stream);
 extern "C" int ctsi_conv3_head_launch(const Conv3HaloParams* hp, int rows, int out_mode, int act, long long sn, long long sc,
                                       long long sd, long long sh, long long sw, void* stream);
+extern "C" int ctsi_conv3_head2_supported(int cin, int cout);
+extern "C" size_t ctsi_conv3_head2_weight_bytes(int cout);
+extern "C" int ctsi_conv3_head2_pack(const float* w, void* packed, int cout, int cin, int cin_w, void* stream);
+extern "C" int ctsi_conv3_head2_launch(const Conv3HaloParams* hp, int n, const void* packed, int out_mode, int act, long long sn,
+                                       long long sc, long long sd, long long sh, long long sw, void* stream);
 extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad, int bn, int transposed);
 extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w, int bn,
                                         int transposed, void* stream);

@@ -204,6 +204,8 @@ class GaussianDiffusion(nn.Module):
             prog.set_diffusion(self)
         loss = train_step(prog, z_0.detach().float(), c.detach().float(), t, noise.float(), norm, m)
         loss_dict = {'mse': loss.item()}
+        prog.check_errors()     # (the stream is synchronised by the .item() above: a sticky split-K hand-off error of this forward,
+                                #  or of the previous step's backward, surfaces here)
         # Optional MS-SSIM term (diffusion.py:204-240).  The reference decodes the predicted z_0 under torch.no_grad(), so the
         # term carries NO gradient: total = (1 - w) * mse + w * (1 - ms_ssim) scales the MSE gradient by (1 - w) and adds a
         # constant.  ms_ssim itself is `pytorch_msssim.ms_ssim` (requirements.txt:24, `pytorch-msssim>=1.0.0`), a third-party

@@ -34,6 +34,8 @@ _CTX: Dict[int, "Ctx"] = {}
 # bf16 per program otherwise -- shares ONE image and packs it once.  Entries are immutable and die with their last user
 # (weak values); a program whose weights changed looks up / packs new images and drops its captured graph.
 _PACKED: Dict[int, "weakref.WeakValueDictionary"] = {}
+# every live program (weak): check_device_errors re-zeroes their split-K hand-off workspaces after a reported device error
+_LIVE_PROGRAMS: "weakref.WeakSet" = weakref.WeakSet()
 
 
 _KEY_CHUNK = 1 << 22
@@ -196,6 +198,8 @@ class Program:
         self._f32_meta: List[dict] = []     # dev_f32 buffers: dict(buf, make, parts, scale, fn)
         self._pack_meta: List[dict] = []    # conv weight images: dict(plan, weight_fn, holder, fn)
         self._fast = None
+        self._sk_workspaces: List[torch.Tensor] = []   # split-K hand-off workspaces (tickets / flags + parked partial sums)
+        _LIVE_PROGRAMS.add(self)
 
     def _emit(self, fn: Callable[[], None], name: str = "op", flops: float = 0.0, kernel: str = "", nbytes: float = 0.0):
         """`nbytes`: algorithmic HBM bytes of an HBM-bound op (what bench.py divides by the launch time for GB/s)."""
@@ -292,7 +296,18 @@ class Program:
         """Device scratch of a split-K conv plan (ctsi_conv_plan_workspace_bytes): one zero-initialised buffer per layer, kept
         for the program's lifetime (the kernel leaves its hand-off tickets reset after every launch)."""
         nbytes = self.lib.conv_plan_workspace_bytes(plan)
-        return self.persistent((nbytes,), torch.uint8, zero=True).data_ptr() if nbytes else 0
+        if not nbytes:
+            return 0
+        ws = self.persistent((nbytes,), torch.uint8, zero=True)
+        self._sk_workspaces.append(ws)
+        return ws.data_ptr()
+
+    def check_errors(self):
+        """Programs with split-K layers: raise if one of their hand-offs failed (see check_device_errors).  The samplers
+        check once per sample() whatever the program holds; the VAE legs and the training step call this, which costs a
+        stream synchronisation only when the program has such a layer at all."""
+        if self._sk_workspaces:
+            check_device_errors(self.ctx)
 
     def persistent(self, shape, dtype, zero=False) -> torch.Tensor:
         t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.ctx.device)
@@ -1257,7 +1272,9 @@ class VAEEncodeProgram(Program):
                                     self.cin_pad, 0, sptr)
         xx.record_stream(self.ctx.stream)
         self.launch()
-        return self.out.clone()
+        out = self.out.clone()
+        self.check_errors()
+        return out
 
 
 class VAEDecodeProgram(VAEEncodeProgram):
@@ -1312,9 +1329,13 @@ class VAEDecodeProgram(VAEEncodeProgram):
         self.load(z)
         if self.shard is None:
             self.launch()
-            return self.out.clone()
+            out = self.out.clone()
+            self.check_errors()
+            return out
         self.run()
-        return self.shard.comm.gather_depth(self.shard.rank, self.out, counts=self.shard.depth_counts)
+        out = self.shard.comm.gather_depth(self.shard.rank, self.out, counts=self.shard.depth_counts)
+        self.check_errors()
+        return out
 
 
 # ==========================================================================================================
@@ -1355,6 +1376,14 @@ def check_device_errors(ctx: Ctx):
     ctx.stream.synchronize()       # the read below is a blocking copy on the null stream, which does not order with ours
     ctx.lib.device_error_status(C.byref(cnt), C.byref(det), 1)
     if cnt.value:
+        # the failed hand-off left its ticket / flag words set (on purpose: a late partner must not meet reset words): start
+        # every split-K layer of every live program on this device from a clean workspace again
+        with torch.cuda.stream(ctx.stream):
+            for prog in list(_LIVE_PROGRAMS):
+                if prog.ctx is ctx:
+                    for ws in prog._sk_workspaces:
+                        ws.zero_()
+        ctx.stream.synchronize()
         raise CtsiError(f"{cnt.value} device-side error(s) recorded by the HIP engine (last: split-K hand-off of conv tile "
                         f"{det.value} timed out); outputs computed since the last check are invalid")
 

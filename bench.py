@@ -478,12 +478,13 @@ def main():
             prog.launch()  # touch everything once (eager)
             prof = prog.profile_ops(repeats=2)
             variants = {}
-            for (_, k, fl, ms) in prof:
+            for i_op, (_, k, fl, ms) in enumerate(prof):
                 if k.startswith("conv_mfma"):
-                    v = variants.setdefault(k, [0, 0.0, 0.0])
+                    v = variants.setdefault(k, [0, 0.0, 0.0, 0.0])
                     v[0] += 1
                     v[1] += fl
                     v[2] += ms
+                    v[3] += prog.op_alg_bytes[i_op] if i_op < len(prog.op_alg_bytes) else 0.0
             step_ms = sum(ms for *_, ms in prof)
             conv_ms = sum(v[2] for v in variants.values())
             conv_fl = sum(v[1] for v in variants.values())
@@ -507,7 +508,15 @@ def main():
                 key = inst.get(dom_key, dom_name.split(" ")[0])
                 ent = next(v for k_, v in pj["kernels"].items() if k_.startswith(key))
                 traffic = ent["hbm_bytes_per_launch"]
-                traffic_source = {"file": PMC_TRAFFIC_FILE, "commit": pj.get("commit"), "method": pj.get("method")}
+                traffic_source = {"file": PMC_TRAFFIC_FILE, "commit": pj.get("commit"), "method": pj.get("method"),
+                                  "FETCH_SIZE_bytes_per_launch": ent["FETCH_SIZE_KB_avg_per_launch"] * 1024.0,
+                                  "WRITE_SIZE_bytes_per_launch": ent["WRITE_SIZE_KB_avg_per_launch"] * 1024.0,
+                                  "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes.  FETCH_SIZE counts "
+                                          "the L2's fabric-side read requests at 64 B each (Infinity-Cache hits included): for this "
+                                          "kernel's halo DMA (32-byte pieces of 256-byte rows, one 16-channel chunk per pass) our "
+                                          "calibration (profiles/r03_fetch_calibration.json) reads between 2 x (every piece its own "
+                                          "request) and 4 x (one tallied request per row), so the read part lies between the figure "
+                                          "given and twice that; it is fabric traffic, not necessarily HBM traffic"}
             except Exception:
                 pass
             # HBM-bound kernels: algorithmic bytes / launch time (same HIP-event pass)
@@ -528,6 +537,8 @@ def main():
                     "traffic_source": traffic_source,
                     "launches_per_step": dom[0], "avg_launch_ms": dom[2] / dom[0],
                     "flops_per_launch_avg": dom[1] / dom[0], "share_of_step_time": dom[2] / step_ms,
+                    "algorithmic_bytes": dom[3] / dom[0],
+                    "traffic_over_algorithmic": (traffic / (dom[3] / dom[0])) if (traffic and dom[3]) else None,
                     "conv_family": {"tflops": conv_fl / (conv_ms * 1e-3) / 1e12,
                                     "frac": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                                     "launches_per_step": sum(v[0] for v in variants.values()),

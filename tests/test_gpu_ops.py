@@ -481,6 +481,35 @@ def test_conv3_head2_kernel(G, monkeypatch, name, cout, dims, f32, act):
             assert torch.equal(y1, F.conv3d(x, w1, None, padding=1)), (name, tap)
 
 
+@pytest.mark.parametrize("order", ["1", "2"])
+@pytest.mark.parametrize("form", ["k3", "convt", "down"])
+def test_k32_tile_orders(G, monkeypatch, form, order):
+    """The alternative block -> tile orders of conv3_halo_k32_kernel (1: depth bands of a tile row innermost, 2: 8 x 4 super-tiles
+    inside a depth band) on a problem with several bands and 8 x 4 tiles per band: same values as the default order (the tile a
+    block owns changes, not its arithmetic), same GroupNorm statistics up to their summation order."""
+    n, cin, cout = 2, 32, 128
+    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
+    if form == "k3":
+        x = bf16_round(formula_input((n, cin, 7, 31, 120), 81))
+        wt = bf16_round(_w((cout, cin, 3, 3, 3), 82))
+        kw = dict()
+    elif form == "convt":
+        x = bf16_round(formula_input((n, cin, 5, 30, 125), 83))
+        wt = bf16_round(_w((cin, cout, 3, 4, 4), 84))
+        kw = dict(transposed=True, k=(3, 4, 4), s=(2, 2))
+    else:
+        x = bf16_round(formula_input((n, cin, 5, 62, 250), 85))
+        wt = bf16_round(_w((cout, cin, 3, 4, 4), 86))
+        kw = dict(k=(3, 4, 4), s=(2, 2))
+    b = formula_input((cout,), 87) * 0.1
+    monkeypatch.setenv("CTSI_CONV_TILE_ORDER", "0")
+    y0, s0 = G.run_conv(x, None, wt, b, want_stats=True, groups=8, **kw)
+    monkeypatch.setenv("CTSI_CONV_TILE_ORDER", order)
+    y1, s1 = G.run_conv(x, None, wt, b, want_stats=True, groups=8, **kw)
+    assert torch.equal(y0, y1)
+    assert torch.allclose(s0, s1, rtol=1e-12, atol=1e-9)
+
+
 def test_conv_linearity_and_zero_padding_property(G):
     """Size-independent properties at a larger shape: conv(a x + y) == a conv(x) + conv(y) up to bf16
     rounding, and an all-ones input with unit centre-tap weights reproduces itself away from borders."""

@@ -166,10 +166,29 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const int cbase = khalf * nchunks;
     const int nb = mt / p.tps;
     int r0 = mt - nb * p.tps;
-    const int tD = r0 / (p.tilesH * p.tilesW);
-    r0 -= tD * p.tilesH * p.tilesW;
-    const int tH = r0 / p.tilesW;
-    const int tW = r0 - tH * p.tilesW;
+    int tD, tH, tW;
+    if (p.tile_order == 1) {
+        // (tH, tD, tW): the depth bands of one tile row innermost -- the two depth-halo slices a tile shares with the band above
+        // are re-read a tile row later instead of a whole band later.  Measured on the VAE decoder (48 x 512^2, 48 x 256^2): no
+        // change in time, FETCH_SIZE +8 % (profiles/r04_notes.md): kept as a switch, not selected
+        tH = r0 / (p.tilesD * p.tilesW);
+        r0 -= tH * p.tilesD * p.tilesW;
+        tD = r0 / p.tilesW;
+        tW = r0 - tD * p.tilesW;
+    } else if (p.tile_order == 2 && (p.tilesW & 3) == 0 && (p.tilesH & 7) == 0) {
+        // 2-D super-tiles of 8 (H) x 4 (W) tiles inside a depth band: the 32 blocks an XCD runs at a time share their H AND W halo
+        // rows in its L2 (the plain order keeps two tile rows of 16 co-resident on 512-wide planes)
+        tD = r0 / (p.tilesH * p.tilesW);
+        r0 -= tD * p.tilesH * p.tilesW;
+        const int st = r0 >> 5, in = r0 & 31, spr = p.tilesW >> 2;
+        tW = (st % spr) * 4 + (in & 3);
+        tH = (st / spr) * 8 + (in >> 2);
+    } else {
+        tD = r0 / (p.tilesH * p.tilesW);
+        r0 -= tD * p.tilesH * p.tilesW;
+        tH = r0 / p.tilesW;
+        tW = r0 - tH * p.tilesW;
+    }
     const int d0 = tD * Cfg::TD, h0 = tH * TH, w0 = tW * TW;
 
     int dlo = d0 + p.dshift - 1;

@@ -1398,6 +1398,13 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
             if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
         }
+        {   // k32 kernel, block -> tile order: 8 x 4 super-tiles inside a depth band (the kernel falls back to the plain order where
+            // the tile grid does not divide): on 512-wide planes the 32 blocks an XCD runs at a time then share H and W halos in its
+            // L2 -- FETCH_SIZE of the VAE decoder's k32 launches -34 %, decode -0.7 ms (profiles/r04_notes.md); identical to the
+            // plain order on the U-Net's 128-wide level (4 tiles per row).  CTSI_CONV_TILE_ORDER = 0 / 1 / 2 overrides (A/B timing)
+            const char* to = getenv("CTSI_CONV_TILE_ORDER");
+            h.tile_order = to ? atoi(to) : 2;
+        }
         if (p->halo3 == 6) {
             // second form (taps as the GEMM's N dimension, input read once straight into the MFMA layout: conv3_head2.hip) for the
             // layers it covers; conv3_head_kernel keeps the others and the GroupNorm column sums.  CTSI_CONV_NO_HEAD2: A/B timing

@@ -137,6 +137,7 @@ struct Conv3HaloParams {
     int* sk_sync;         //   [tile][2]: ticket, ready flag (zero before the first launch; the kernel resets them)
     int tr;               // conv3_halo_k32_kernel: ConvTranspose3d (3,4,4) / (1,2,2): Do/Ho/Wo are the OUTPUT dims, tiles walk the input grid
     int ds;               // conv3_halo_k32_kernel: strided Conv3d (3,4,4) / (1,2,2): tiles walk the OUTPUT grid, nchunks = 4 * Cin / 16
+    int tile_order;       // conv3_halo_k32_kernel: 0 = (tD, tH, tW); 1 = (tH, tD, tW); 2 = 8 x 4 super-tiles inside a depth band (see its tile decode)
     int nt_store;         // conv3_halo_k32_kernel: non-temporal output stores (large outputs: keep the L2 for halos and weights)
 };
 

@@ -175,6 +175,7 @@ class Program:
         self.ops: List[Callable[[], None]] = []
         self.op_meta: List[Tuple[str, float, str]] = []
         self.op_bytes: List[float] = []
+        self.op_alg_bytes: List[float] = []   # convs: algorithmic HBM bytes (inputs + outputs + weights, each once)
         self.pool = _Pool(ctx.device)
         self.keep: List[object] = []       # tensors / ctypes structs that must outlive the ops
         self.plans: List[C.c_void_p] = []  # conv plan handles (destroyed with the program)
@@ -201,11 +202,13 @@ class Program:
         self._sk_workspaces: List[torch.Tensor] = []   # split-K hand-off workspaces (tickets / flags + parked partial sums)
         _LIVE_PROGRAMS.add(self)
 
-    def _emit(self, fn: Callable[[], None], name: str = "op", flops: float = 0.0, kernel: str = "", nbytes: float = 0.0):
+    def _emit(self, fn: Callable[[], None], name: str = "op", flops: float = 0.0, kernel: str = "", nbytes: float = 0.0,
+              alg_bytes: float = 0.0):
         """`nbytes`: algorithmic HBM bytes of an HBM-bound op (what bench.py divides by the launch time for GB/s)."""
         self.ops.append(fn)
         self.op_meta.append((name, flops, kernel))
         self.op_bytes.append(float(nbytes))
+        self.op_alg_bytes.append(float(alg_bytes))
 
     # ---- buffers -------------------------------------------------------------------------------------
     def act(self, n, c, d, h, w, halo: Optional[int] = None) -> Act:
@@ -612,7 +615,11 @@ class Program:
         form = "t" if transposed else ("d" if tuple(s) == (2, 2) else "")        # t: ConvTranspose form, d: Downsample form,
         kernel = "conv_mfma_%dx%d_m%d%s%s" % (bm.value, bn.value, mode.value, form if mode.value == 9 else "",
                                               "s" if co.workspace else "")      # s: split-K form
-        self._emit(run, name, fl, kernel)
+        cin_all = x1.c + (0 if x2 is None else x2.c)
+        alg = (2.0 * x1.n * di * x1.h * x1.w * cin_all + float(wbytes)
+               + (4.0 if f32_out is not None else 2.0) * x1.n * do * ho * wo * cout
+               + (2.0 * x1.n * do * ho * wo * cout if fuse_gn is not None else 0.0))
+        self._emit(run, name, fl, kernel, alg_bytes=alg)
         return out_act, stats
 
     def _conv_overlapped(self, name, weight_fn, bias_fn, x1: Act, x2: Optional[Act], k, p, cout, cin_w, want_stats):

@@ -444,6 +444,9 @@ def main():
     pkg = importlib.import_module("video-to-video-diffusion_amd")
     S = importlib.import_module("video-to-video-diffusion_amd.sampler")
     E = importlib.import_module("video-to-video-diffusion_amd.engine")
+    if pkg.get_lib().ablation_build():
+        # libctsi_ablate.so (`make ablate`) carries switches that let a kernel skip work: no number is taken from it
+        raise SystemExit("bench.py: CTSI_LIB points at an ablation build (timing-only switches compiled in); refusing to time it")
 
     torch.manual_seed(0)
     model = pkg.VideoToVideoDiffusion(EFFECTIVE_CFG if args.model == "effective" else LEGACY163_CFG).eval().to(dev)

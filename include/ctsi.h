@@ -37,6 +37,9 @@ extern "C" {
 
 /* library / error handling ------------------------------------------------------------ */
 int ctsi_version(void);
+/* 1 for a build with the timing-only ablation switches compiled in (`make ablate`: libctsi_ablate.so, for tools/ only:
+ * CTSI_DEBUG_FLAGS / CTSI_DEBUG_KSTEPS can make its kernels skip work); 0 for the release library, which ignores them. */
+int ctsi_ablation_build(void);
 const char* ctsi_last_error(void);
 /* 1 when a HIP device is visible to this process, 0 otherwise (never raises). */
 int ctsi_device_available(void);

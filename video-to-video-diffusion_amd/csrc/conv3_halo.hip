@@ -258,12 +258,12 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
         // the pieces are issued) unless p.dbg & 16 (old placement, right behind the barrier: A/B timing)
 #define H32_ISSUE()                                                                                            \
         {                                                                                                      \
-            if (s + 2 < S && !(p.dbg & 2)) issue_weights(s + 2, OFF_W + (s & 1) * WSLOT_BYTES);                \
-            halo_in_flight = (g < NPIECE - 1) && (cc + 1 < nchunks) && !(p.dbg & 1) && (wave + 8 * g < HALO_INSTR); \
-            if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1)) issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES); \
+            if (s + 2 < S && !(CTSI_DBG(p.dbg, 2))) issue_weights(s + 2, OFF_W + (s & 1) * WSLOT_BYTES);                \
+            halo_in_flight = (g < NPIECE - 1) && (cc + 1 < nchunks) && !(CTSI_DBG(p.dbg, 1)) && (wave + 8 * g < HALO_INSTR); \
+            if (g < NPIECE && cc + 1 < nchunks && !(CTSI_DBG(p.dbg, 1))) issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES); \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
         }
-        if (p.dbg & 16) H32_ISSUE();
+        if (CTSI_DBG(p.dbg, 16)) H32_ISSUE();
         int g2 = g + 1, cc2 = cc;
         if (g2 == 9) {
             g2 = 0;
@@ -278,9 +278,9 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
         H32_PHASE(fa1, fb1, fa0, fb0, hbuf2, wbuf2, vs2, 0, true);
         // SIMD partners (waves w, w + 4) issue their pieces at different phase boundaries (+1.7-2.4 %, profiles/r02_notes.md):
         // while one issues -- and feeds no MFMAs -- the other runs a phase on the matrix pipe (p.dbg & 32: all waves here)
-        if (!(p.dbg & 16) && (wave < 4 || (p.dbg & 32))) H32_ISSUE();
+        if (!(CTSI_DBG(p.dbg, 16)) && (wave < 4 || (CTSI_DBG(p.dbg, 32)))) H32_ISSUE();
         H32_PHASE(fa2, fb2, fa1, fb1, hbuf2, wbuf2, vs2, 1, true);
-        if (!(p.dbg & 16) && wave >= 4 && !(p.dbg & 32)) H32_ISSUE();
+        if (!(CTSI_DBG(p.dbg, 16)) && wave >= 4 && !(CTSI_DBG(p.dbg, 32))) H32_ISSUE();
         g = g2;
         cc = cc2;
     }
@@ -291,7 +291,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
     __syncthreads();
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
-    if (p.dbg & 8) return;
+    if (CTSI_DBG(p.dbg, 8)) return;
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16 = 64 KB
     const bool want_sums = p.colsum != nullptr;
     const int lhi = lane >> 5, lcol = lane & 31;
@@ -374,7 +374,7 @@ conv3_halo32_kernel(const Conv3HaloParams p) {
             const int row = c / CPR, ch = c - row * CPR;
             const long long off = s_rowoff[row];
             const int co = n0 + ch * 8;
-            if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
+            if (off >= 0 && co < p.Cout && !(CTSI_DBG(p.dbg, 4))) {
                 const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
                 *reinterpret_cast<uint4*>(y + off + co) = v;
             }

@@ -112,7 +112,7 @@ __device__ unsigned int g_hk_device_error[2] = {0u, 0u};
 #define HK_NSTAMP 4096
 __device__ unsigned long long g_hk_stamps[HK_NSTAMP][8];
 #define HK_STAMP(K)                                                                                              \
-    if ((p.dbg & 4096) && tid == 0 && blockIdx.x < HK_NSTAMP) g_hk_stamps[blockIdx.x][K] = __builtin_amdgcn_s_memtime();
+    if ((CTSI_DBG(p.dbg, 4096)) && tid == 0 && blockIdx.x < HK_NSTAMP) g_hk_stamps[blockIdx.x][K] = __builtin_amdgcn_s_memtime();
 
 template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false, bool SK = false, bool DS = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, 512)))
@@ -137,7 +137,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     HK_STAMP(0);
-    if ((p.dbg & 4096) && tid == 0 && blockIdx.x < HK_NSTAMP)
+    if ((CTSI_DBG(p.dbg, 4096)) && tid == 0 && blockIdx.x < HK_NSTAMP)
         g_hk_stamps[blockIdx.x][7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32) |
                                      (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
     int bid = xcd_remap_h(blockIdx.x, gridDim.x);
@@ -423,7 +423,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     auto issue_group = [&](int s) {
         int n_halo = 0, n_w = 0;
         bool urgent = false;
-        if (hc < nchunks && s >= hfree && !(p.dbg & 1)) {
+        if (hc < nchunks && s >= hfree && !(CTSI_DBG(p.dbg, 1))) {
             // the chunk's first entry TAPS hc lies in unit (TAPS hc) >> 1 = step S': it is first read behind B_{S' - 1}
             urgent = s + 2 >= ((TAPS * hc) >> 1) / UPS;
             const int cnt = hp == 0 ? H_FIRST : H_LATER;
@@ -439,7 +439,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
                 ++hc;
             }
         }
-        if (s + NWS - 1 < S && !(p.dbg & 2)) {
+        if (s + NWS - 1 < S && !(CTSI_DBG(p.dbg, 2))) {
             issue_weights(s + NWS - 1);
             n_w = 2;
         }
@@ -475,14 +475,14 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             HK_UNIT(fa0, fa1, baddr, 2, baddr, 3, an[2], );
         }
         hk_wait_vm(n_prev);
-        if (!(p.dbg & 64)) __builtin_amdgcn_s_barrier();      // (64: timing-only ablation)
+        if (!(CTSI_DBG(p.dbg, 64))) __builtin_amdgcn_s_barrier();      // (64: timing-only ablation)
         __builtin_amdgcn_sched_barrier(0);
         // SIMD partners (waves w and w + 4) issue their pieces at DIFFERENT phase boundaries: a piece costs its wave ~60-100 issue
         // cycles during which it feeds no MFMAs, so waves 0-3 issue behind the first MFMA phase after the barrier -- while waves
         // 4-7 run their second phase on the matrix pipe -- and waves 4-7 behind that second phase (p.dbg & 16: all waves at the
         // first boundary, for A/B timing: 5-6 % slower on real data, 12-14 % on zeros)
-        HK_UNIT(fa1, fa0, baddr, UPS - 1, baddr_n, 0, an[UPS - 1], if (wave < 4 || (p.dbg & 16)) issue_group(s));
-        if (wave >= 4 && !(p.dbg & 16)) issue_group(s);
+        HK_UNIT(fa1, fa0, baddr, UPS - 1, baddr_n, 0, an[UPS - 1], if (wave < 4 || (CTSI_DBG(p.dbg, 16))) issue_group(s));
+        if (wave >= 4 && !(CTSI_DBG(p.dbg, 16))) issue_group(s);
     }
 #undef HK_UNIT
 #undef HK_LOAD_A
@@ -496,7 +496,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
 
     // ---- epilogue: bias, GroupNorm column sums, the 512 x 128 bf16 tile through LDS (128 KB), 16-byte row stores -----
     // accumulator (i, j)[q]: row 16 i + 4 kg + q of the wave's 64, cout 16 j + r16
-    if (p.dbg & 8) return;
+    if (CTSI_DBG(p.dbg, 8)) return;
     if (SK) {
         const int tile = mt * p.ntiles_n + nt;
         constexpr int NREG = MA * NJ * 4;
@@ -632,7 +632,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             const int row = wave * RPW + c / CPR, ch = c % CPR;
             const long long off = s_rowoff[row];
             const int co = n0 + ch * 8;
-            if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
+            if (off >= 0 && co < p.Cout && !(CTSI_DBG(p.dbg, 4))) {
                 const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BNP + ch * 8);
                 if (p.nt_store) {     // streaming (non-temporal) stores: see ctsi_conv_fwd
                     typedef unsigned int u4_t __attribute__((ext_vector_type(4)));

@@ -109,7 +109,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long* s_rowoff = reinterpret_cast<long long*>(smem + NSTG * STAGE);
 
-    if (p.dbg & 8) return;
+    if (CTSI_DBG(p.dbg, 8)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -424,7 +424,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
             slot = (slot + 1 == NSTG) ? 0 : slot + 1;
         }
     } else {
-        if (!(p.dbg & 4) && S > 0) stage(s_begin, smem);
+        if (!(CTSI_DBG(p.dbg, 4)) && S > 0) stage(s_begin, smem);
         for (int s = 0; s < S; ++s) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -434,7 +434,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         }
     }
     __syncthreads();  // every wave is done with the stage buffers
-    if (p.dbg & 2) return;
+    if (CTSI_DBG(p.dbg, 2)) return;
     if constexpr (TM == 2 && TN == 2)          // (the host splits 128 x 128-tile plans only: keep the other forms' code lean)
     if (nsplit > 1) {
         // Split-K hand-off, S-way (conv3_halo_k32.hip has the 2-way form): every block parks its accumulators with agent-scope
@@ -676,7 +676,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
                 const int row = c / CPR, cc = c - row * CPR;
                 const long long off = s_rowoff[row];
                 const int co = n0 + cc * 8;
-                if (off >= 0 && co < p.Cout && !(p.dbg & 1)) {
+                if (off >= 0 && co < p.Cout && !(CTSI_DBG(p.dbg, 1))) {
                     const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + cc * 8);
                     *reinterpret_cast<uint4*>(y + off + co) = v;
                 }
@@ -1393,10 +1393,8 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             if (p->d.transposed && !nm) h.n_major = 4;
         }
         {
-            const char* dbgf = getenv("CTSI_DEBUG_FLAGS");      // (read per launch: tools/ab_variants.py alternates them)
-            h.dbg = dbgf ? atoi(dbgf) : 0;
-            static const char* dbgk = getenv("CTSI_DEBUG_KSTEPS");
-            if (dbgk && atoi(dbgk) < h.nchunks) h.nchunks = atoi(dbgk);   // timing-only: truncate the chunk loop
+            h.dbg = ctsi_debug_flags();                 // release library: the timeline bit only (ctsi_internal.h)
+            h.nchunks = ctsi_debug_ksteps(h.nchunks);   // ablation builds only: truncate the chunk loop
         }
         {   // k32 kernel, block -> tile order: 8 x 4 super-tiles inside a depth band (the kernel falls back to the plain order where
             // the tile grid does not divide): on 512-wide planes the 32 blocks an XCD runs at a time then share H and W halos in its
@@ -1462,12 +1460,8 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
         grid *= p->gsplit;
     }
     hipStream_t st = (hipStream_t)stream;
-    {   // timing-only ablation knob (wrong results): truncate the K loop to price prologue + epilogue
-        static const char* dbg = getenv("CTSI_DEBUG_KSTEPS");
-        if (dbg) k.ksteps = atoi(dbg) < k.ksteps ? atoi(dbg) : k.ksteps;
-        static const char* dbgf = getenv("CTSI_DEBUG_FLAGS");
-        k.dbg = dbgf ? atoi(dbgf) : 0;
-    }
+    k.ksteps = ctsi_debug_ksteps(k.ksteps);   // (ablation builds only: truncate the K loop to price prologue + epilogue)
+    k.dbg = ctsi_debug_flags();
     k.gn_x = (const bf16_t*)o->gn_x;
     k.gn_sums = o->gn_sums;
     k.gn_gamma = o->gn_gamma;

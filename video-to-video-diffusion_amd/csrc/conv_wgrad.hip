@@ -468,7 +468,7 @@ conv_wgrad_s1_kernel(const WgradParams p) {
                 for (int t = 0; t < TG; ++t) {
                     vmask[t] = __builtin_amdgcn_ballot_w64(dh && (unsigned)(w - p.pw + t) < (unsigned)p.Wg);
                     if (BK == 32) vmask[t] |= 0xffffffff00000000ull;
-                    if (p.dbg & 2) vmask[t] = ~0ull;
+                    if (CTSI_DBG(p.dbg, 2)) vmask[t] = ~0ull;
                 }
             }
             const unsigned sb = lds0 + stage * STAGE;
@@ -487,7 +487,7 @@ conv_wgrad_s1_kernel(const WgradParams p) {
                     } else {
                         wg_wait_vm<0>();
                     }
-                    if (!(p.dbg & 64)) __builtin_amdgcn_s_barrier();
+                    if (!(CTSI_DBG(p.dbg, 64))) __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     if (ks + 1 < k_end) WG_LOAD(0, lds0 + nstage * STAGE, 0);   // (NSUB is even: the last sub-step computes on set 1)
                 } else {
@@ -497,8 +497,8 @@ conv_wgrad_s1_kernel(const WgradParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 // refill of this step's stage (free since the barrier above): waves 0-3 behind the last sub-step, waves 4-7 behind
                 // the next step's first one
-                if (sub == NSUB - 1 && refill && wv < 4 && !(p.dbg & 1)) issue(ks + NS, stage);
-                if (sub == 0 && wv >= 4 && ks > k_begin && ks - 1 + NS < k_end && !(p.dbg & 1))
+                if (sub == NSUB - 1 && refill && wv < 4 && !(CTSI_DBG(p.dbg, 1))) issue(ks + NS, stage);
+                if (sub == 0 && wv >= 4 && ks > k_begin && ks - 1 + NS < k_end && !(CTSI_DBG(p.dbg, 1)))
                     issue(ks - 1 + NS, stage == 0 ? NS - 1 : stage - 1);
             }
             stage = nstage;
@@ -744,10 +744,7 @@ extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* g
     p.KH = d->kh; p.KW = d->kw; p.sh = d->sh; p.sw = d->sw; p.pd = d->pd; p.ph = d->ph; p.pw = d->pw;
     p.T = g.T; p.tiles_r = g.tiles_r; p.tiles_g = g.tiles_g; p.S = g.S; p.ksteps = g.ksteps; p.kps = g.kps;
     p.V = (int)g.V;
-    {
-        const char* dbgf = getenv("CTSI_DEBUG_FLAGS");   // (read per launch)
-        p.dbg = dbgf ? atoi(dbgf) : 0;
-    }
+    p.dbg = ctsi_debug_flags();
     wg_magic((unsigned)d->wr, &p.mW, &p.shW);
     wg_magic((unsigned)d->hr, &p.mH, &p.shH);
     wg_magic((unsigned)d->dr, &p.mD, &p.shD);

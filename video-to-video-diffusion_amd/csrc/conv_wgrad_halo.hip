@@ -237,7 +237,7 @@ conv_wgrad_halo_kernel(const WgradHaloParams p) {
             const int stage = (tile - t_begin) & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                    // tile landed; every wave is done with the other stage
-            const bool more = tile + 1 < t_end && !(p.dbg & 1);
+            const bool more = tile + 1 < t_end && !(CTSI_DBG(p.dbg, 1));
             const Origin on = tile_origin(more ? tile + 1 : tile);
             const unsigned sb = lds0 + stage * STAGE, nb_ = lds0 + (stage ^ 1) * STAGE;
             bf16x8 bfr[4], bnx[4], af[3];
@@ -362,10 +362,7 @@ extern "C" int ctsi_wgrad_halo_launch(const void* X, const void* dY, void* part,
     p.N = n; p.D = d; p.H = h; p.W = w;
     p.tilesD = pl.tilesD; p.tilesH = pl.tilesH; p.tilesW = pl.tilesW; p.ntiles = pl.ntiles;
     p.nchunks = pl.nchunks; p.ncot = pl.ncot; p.S = pl.S; p.tps = pl.tps; p.CRp = pl.CRp; p.CGp = pl.CGp;
-    {
-        const char* dbgf = getenv("CTSI_DEBUG_FLAGS");   // (read per launch)
-        p.dbg = dbgf ? atoi(dbgf) : 0;
-    }
+    p.dbg = ctsi_debug_flags();
     const int blocks = pl.nchunks * pl.ncot * pl.S;
     if (pl.code == 1) wh_launch<3, 8, 8>(p, blocks, (hipStream_t)stream);
     else if (pl.code == 2) wh_launch<6, 4, 8>(p, blocks, (hipStream_t)stream);

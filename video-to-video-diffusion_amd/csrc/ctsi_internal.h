@@ -56,6 +56,21 @@ struct CtsiPerDeviceOnce {
         }                                                                               \
     } while (0)
 
+// ---- timing-only ablation switches ---------------------------------------------------------------
+// CTSI_DEBUG_FLAGS bits that make a kernel skip work (DMAs, barriers, stores, the epilogue: wrong results by design) and
+// CTSI_DEBUG_KSTEPS exist only in builds with -DCTSI_ABLATE (`make ablate` -> libctsi_ablate.so, which tools/ load through
+// CTSI_LIB).  In the release library every such test is a compile-time 0 and the environment is not consulted for them;
+// only bit 4096 (conv3_halo_k32_kernel's in-kernel timeline: correct results) survives.
+#ifdef CTSI_ABLATE
+#define CTSI_DBG(flags, bit) ((flags) & (bit))
+#define CTSI_DBG_MASK (~0)
+#else
+#define CTSI_DBG(flags, bit) (((bit) == 4096) ? ((flags) & 4096) : 0)
+#define CTSI_DBG_MASK 4096
+#endif
+int ctsi_debug_flags();        // CTSI_DEBUG_FLAGS & CTSI_DBG_MASK, read per call (runtime.hip)
+int ctsi_debug_ksteps(int n);  // min(n, CTSI_DEBUG_KSTEPS) in ablation builds, n otherwise
+
 // ---- device helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
     return __uint_as_float(((uint32_t)v) << 16);

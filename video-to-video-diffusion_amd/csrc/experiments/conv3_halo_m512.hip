@@ -303,20 +303,20 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
            s+1 (issued 3 steps ago); the next chunk's halo pieces are issued at g < NPIECE <= 6, so they are   \
            older than the two most recent steps' DMAs by the time they are read (g = 8). */                    \
         hm_wait_vm(n_prev1 + n_prev2);                                                                         \
-        if (!(p.dbg & 64)) __builtin_amdgcn_s_barrier();   /* (64: timing-only ablation) */                    \
+        if (!(CTSI_DBG(p.dbg, 64))) __builtin_amdgcn_s_barrier();   /* (64: timing-only ablation) */                    \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
 #define HM_ISSUE()                                                                                             \
     {                                                                                                          \
         int issued = 0;                                                                                        \
-        if (s + NWS < S && !(p.dbg & 2)) issued += issue_weights(s + NWS);                                     \
-        if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1))                                                    \
+        if (s + NWS < S && !(CTSI_DBG(p.dbg, 2))) issued += issue_weights(s + NWS);                                     \
+        if (g < NPIECE && cc + 1 < nchunks && !(CTSI_DBG(p.dbg, 1)))                                                    \
             issued += issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);                                      \
         n_prev2 = n_prev1;                                                                                     \
         n_prev1 = issued;                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
-    const bool issue_early = (p.dbg & 16) != 0, issue_last = (p.dbg & 32) != 0;
+    const bool issue_early = (CTSI_DBG(p.dbg, 16)) != 0, issue_last = (CTSI_DBG(p.dbg, 32)) != 0;
     for (int s = 0; s < S; ++s) {
         const char* hbuf = smem + (cc & 1) * HALO_BYTES;
         const char* wbuf = smem + OFF_W + (s % NWS) * WSLOT_BYTES;
@@ -363,7 +363,7 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
     __syncthreads();
 
     // ---- epilogue: bias, GroupNorm column sums, the 512 x 128 bf16 tile through LDS (128 KB), 16-byte row stores -----
-    if (p.dbg & 8) return;
+    if (CTSI_DBG(p.dbg, 8)) return;
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16
     const bool want_sums = p.colsum != nullptr;
     const int lhi = lane >> 5, lcol = lane & 31;
@@ -426,7 +426,7 @@ conv3_halo32m_kernel(const Conv3HaloParams p) {
             const int row = c / CPR, ch = c - row * CPR;
             const long long off = s_rowoff[row];
             const int co = n0 + ch * 8;
-            if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
+            if (off >= 0 && co < p.Cout && !(CTSI_DBG(p.dbg, 4))) {
                 const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
                 *reinterpret_cast<uint4*>(y + off + co) = v;
             }

@@ -216,8 +216,8 @@ conv3_halo32n_kernel(const Conv3HaloParams p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         int issued = 0;
-        if (s + NWS < S && !(p.dbg & 2)) issued += issue_weights(s + NWS);
-        if (g < NPIECE && cc + 1 < nchunks && !(p.dbg & 1)) issued += issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
+        if (s + NWS < S && !(CTSI_DBG(p.dbg, 2))) issued += issue_weights(s + NWS);
+        if (g < NPIECE && cc + 1 < nchunks && !(CTSI_DBG(p.dbg, 1))) issued += issue_halo(cc + 1, g, ((cc + 1) & 1) * HALO_BYTES);
         n_prev2 = n_prev1;
         n_prev1 = issued;
         int g2 = g + 1, cc2 = cc;
@@ -242,7 +242,7 @@ conv3_halo32n_kernel(const Conv3HaloParams p) {
     __syncthreads();
 
     // ---- epilogue: bias, bf16 tile through LDS, 16-byte row stores, GroupNorm column sums ---------------------------
-    if (p.dbg & 8) return;
+    if (CTSI_DBG(p.dbg, 8)) return;
     bf16_t* s_tile = reinterpret_cast<bf16_t*>(smem);  // [BM][BN] bf16 = 32 KB
     const bool want_sums = p.colsum != nullptr;
     const int lhi = lane >> 5, lcol = lane & 31;
@@ -305,7 +305,7 @@ conv3_halo32n_kernel(const Conv3HaloParams p) {
             const int row = c / CPR, ch = c - row * CPR;
             const long long off = s_rowoff[row];
             const int co = n0 + ch * 8;
-            if (off >= 0 && co < p.Cout && !(p.dbg & 4)) {
+            if (off >= 0 && co < p.Cout && !(CTSI_DBG(p.dbg, 4))) {
                 const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + ch * 8);
                 *reinterpret_cast<uint4*>(y + off + co) = v;
             }

@@ -287,7 +287,7 @@ conv3_halo32p_kernel(const Conv3HaloParams p, const int total_tiles) {
         }
 
         // ---- epilogue of the finished tile, straight from the accumulators ------------------------------------------
-        if (!(p.dbg & 8)) {
+        if (!(CTSI_DBG(p.dbg, 8))) {
             const long long* s_rowoff = reinterpret_cast<const long long*>(smem + OFF_ROW + rbuf * ROW_BYTES);
             bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
             const bool want_sums = p.colsum != nullptr;
@@ -307,7 +307,7 @@ conv3_halo32p_kernel(const Conv3HaloParams p, const int total_tiles) {
                         if (off >= 0) {
                             s1 += v;
                             s2 += v * v;
-                            if (cok && !(p.dbg & 4)) y[off + co] = f32_to_bf16(v);
+                            if (cok && !(CTSI_DBG(p.dbg, 4))) y[off + co] = f32_to_bf16(v);
                         }
                     }
                 }

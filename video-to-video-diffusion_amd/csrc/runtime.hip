@@ -12,6 +12,27 @@ void ctsi_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Timing-only ablation switches: see ctsi_internal.h.  The release library honours bit 4096 (in-kernel timeline) only.
+int ctsi_debug_flags() {
+    const char* f = getenv("CTSI_DEBUG_FLAGS");   // read per call: tools/ab_variants.py alternates values in one process
+    return f ? (atoi(f) & CTSI_DBG_MASK) : 0;
+}
+int ctsi_debug_ksteps(int n) {
+#ifdef CTSI_ABLATE
+    const char* k = getenv("CTSI_DEBUG_KSTEPS");
+    if (k && atoi(k) < n) return atoi(k);
+#endif
+    return n;
+}
+// 1 when the library was built with -DCTSI_ABLATE (libctsi_ablate.so): bench.py refuses to time such a build
+extern "C" int ctsi_ablation_build(void) {
+#ifdef CTSI_ABLATE
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int ctsi_version(void) { return 100; }
 extern "C" const char* ctsi_last_error(void) { return g_err; }
 

@@ -69,6 +69,7 @@ _ip = C.POINTER(C.c_int)
 # name -> (restype, argtypes, returns_status)
 SIGNATURES = {
     "ctsi_version": (_i, [], False),
+    "ctsi_ablation_build": (_i, [], False),
     "ctsi_last_error": (C.c_char_p, [], False),
     "ctsi_device_available": (_i, [], False),
     "ctsi_ncdhw_f32_to_ndhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp], True),

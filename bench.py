@@ -45,7 +45,7 @@ LEGACY163_CFG = {  # the flat config behind the "163 M-param U-Net" of the refer
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable with a float4 copy)
-PMC_TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")   # written by tools/pmc_traffic.py (records its commit)
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")   # written by tools/pmc_traffic.py (records its commit)
 PMC_TRAFFIC_TRAIN_FILE = os.path.join("profiles", "r03_pmc_traffic_train.json")   # the same over tools/profile_train.py
 
 
@@ -82,15 +82,58 @@ def parse():
     return ap.parse_args()
 
 
+def _cgroup_cpu_quota():
+    """CPUs the container's cgroup may use (cpu.max of cgroup v2, cfs quota of v1), or None when unlimited / unreadable."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return max(1, int(int(quota) / int(period) + 0.5))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        if quota > 0:
+            return max(1, int(quota / period + 0.5))
+    except Exception:
+        pass
+    return None
+
+
 def _host_cores():
-    """(cores this process may run on, cores of the host): the GPU boxes hand a container a CPU share, so the affinity mask
-    -- not os.cpu_count() -- is what 'all cores' means here."""
+    """(cores this process may use, cores of the host).  The GPU boxes hand a container a CPU SHARE of a 256-core host: the
+    affinity mask still lists every core, the cgroup quota is what limits the process (256 oracle threads on a 16-CPU share
+    took 108 s for the evaluation 16 threads finish in 23 s).  So: affinity mask, cut to the cgroup quota; if neither limits
+    anything on a large host, a short probe picks between all cores and 16."""
     total = os.cpu_count() or 1
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = total
-    return max(1, min(avail, total)), total
+    avail = max(1, min(avail, total))
+    quota = _cgroup_cpu_quota()
+    if quota is not None:
+        avail = min(avail, quota)
+    elif avail > 32:
+        import torch.nn.functional as F
+        x = torch.randn(1, 64, 16, 64, 64)
+        w = torch.randn(64, 64, 3, 3, 3)
+        best = None
+        for n in (avail, 16):
+            torch.set_num_threads(n)
+            with torch.no_grad():
+                F.conv3d(x, w, padding=1)
+                t0 = time.time()
+                for _ in range(3):
+                    F.conv3d(x, w, padding=1)
+                dt = time.time() - t0
+            if best is None or dt < best[0]:
+                best = (dt, n)
+        avail = best[1]
+    return avail, total
 
 
 def cpu_baseline(threads, latent_hw, depth, config1=False):
@@ -501,7 +544,7 @@ def main():
             # PMC counters cannot be collected inside this process: `traffic` is the per-launch HBM byte count of the
             # dominant kernel from the last committed rocprofv3 --pmc passes over the same workload; the file records the
             # commit it was measured at.  null when no such file exists.
-            traffic, traffic_source = None, None
+            traffic, traffic_source, traffic_cal = None, None, None
             try:
                 pj = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_FILE)))
                 # the profile lists template instantiations: the bench's variant key names the tile (512x128 = <4, 4, 32, ...>)
@@ -511,7 +554,9 @@ def main():
                 key = inst.get(dom_key, dom_name.split(" ")[0])
                 ent = next(v for k_, v in pj["kernels"].items() if k_.startswith(key))
                 traffic = ent["hbm_bytes_per_launch"]
+                traffic_cal = ent.get("hbm_bytes_calibrated")
                 traffic_source = {"file": PMC_TRAFFIC_FILE, "commit": pj.get("commit"), "method": pj.get("method"),
+                                  "fetch_factor_calibrated": ent.get("fetch_factor_calibrated"),
                                   "FETCH_SIZE_bytes_per_launch": ent["FETCH_SIZE_KB_avg_per_launch"] * 1024.0,
                                   "WRITE_SIZE_bytes_per_launch": ent["WRITE_SIZE_KB_avg_per_launch"] * 1024.0,
                                   "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes.  FETCH_SIZE counts "
@@ -542,6 +587,9 @@ def main():
                     "flops_per_launch_avg": dom[1] / dom[0], "share_of_step_time": dom[2] / step_ms,
                     "algorithmic_bytes": dom[3] / dom[0],
                     "traffic_over_algorithmic": (traffic / (dom[3] / dom[0])) if (traffic and dom[3]) else None,
+                    # the same with the FETCH_SIZE factor calibrated for this kernel's access shape (tools/pmc_traffic.py): an upper bound
+                    "traffic_calibrated": traffic_cal,
+                    "traffic_calibrated_over_algorithmic": (traffic_cal / (dom[3] / dom[0])) if (traffic_cal and dom[3]) else None,
                     "conv_family": {"tflops": conv_fl / (conv_ms * 1e-3) / 1e12,
                                     "frac": conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                                     "launches_per_step": sum(v[0] for v in variants.values()),

@@ -115,6 +115,13 @@ int ctsi_conv_plan_create(ctsi_conv_plan** plan, const ctsi_conv_desc* desc);
 /* the weight tensor carries only `cin_w` (< c1+c2) input channels; the remaining activation
  * channels are layout padding (the 1-channel CT volume is stored with 8 channels).       */
 int ctsi_conv_plan_set_weight_cin(ctsi_conv_plan* plan, int cin_w);
+/* A 1x1x1 stride-1 layer that will run with the fused GroupNorm tail (ctsi_conv_out.gn_x: the ResBlock tails of
+ * models/unet3d.py:102, 112-133) or as a plain bf16 conv + bias may take the streaming kernel (csrc/conv1_stream.hip: weights
+ * resident in LDS, every voxel row read once straight into the MFMA layout).  Call it BEFORE ctsi_conv_plan_weight_bytes /
+ * _pack_weights: the packed image differs.  on = 1 selects it where the layer qualifies (every source a multiple of 128
+ * channels, K = 128 .. 512, 768 or 1024, cout in whole n-tiles) and is a no-op otherwise; ctsi_conv_plan_config reports
+ * mode 10 when it is active.  Such a plan emits no column sums and no activation.                                  */
+int ctsi_conv_plan_set_stream_tail(ctsi_conv_plan* plan, int on);
 void ctsi_conv_plan_destroy(ctsi_conv_plan* plan);
 /* output spatial size of the layer */
 int ctsi_conv_plan_out_dims(const ctsi_conv_plan* plan, int* d_out, int* h_out, int* w_out);
@@ -277,7 +284,10 @@ int ctsi_weight_dgrad_layout(const float* w, float* out, int cout, int cin, int 
  * given, dtbias[n][c] (row stride dtbias_stride) = per-sample channel sums of the gradient after the outer SiLU, and,
  * when dxsum is given, dxsum[c] = sum over samples and voxels of dx (before `add`) = the bias gradient of the
  * convolution that produced x, evaluated in fp32 from the statistics instead of re-reading dx.
- * workspace: ctsi_gn_bwd_workspace_floats() floats. */
+ * g_buf may be NULL when there is neither a residual nor an outer SiLU (nothing but dx needs that gradient: the second pass
+ * re-derives it from dy; same dx bit for bit, one tensor write less).
+ * workspace: ctsi_gn_bwd_workspace_floats() floats (the statistics tile shrinks from 512 rows for small tensors, so that
+ * function -- not ctsi_gn_bwd_tiles, the tile count at 512 rows -- sizes it). */
 int ctsi_gn_bwd_tiles(int d, int h, int w);
 size_t ctsi_gn_bwd_workspace_floats(int n, int c, int d, int h, int w, int groups);
 int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const double* sums, const float* gamma,

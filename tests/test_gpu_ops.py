@@ -799,6 +799,66 @@ def test_layout_roundtrip_and_nan_guard(G):
     assert f.cpu().tolist() == [1.0, 0.0, 1.0, -1.0, -2.5]
 
 
+TAIL_CASES = [
+    # name, c1, c2, cout, (n, d, h, w), silu, forced n-tile width (16-cout tiles) or None
+    ("128_to_256_ragged_voxels", 128, 0, 256, (1, 3, 9, 7), True, None),          # 1 chunk, 256-cout n-tile; 189 voxels (tile tail)
+    ("256+128_to_128_batch2", 256, 128, 128, (2, 2, 8, 8), True, None),           # 3 chunks, two sources, two samples
+    ("256_to_512_two_ntiles", 256, 0, 512, (1, 2, 6, 5), True, None),             # 2 chunks, two 256-cout n-tiles
+    ("256_to_512_nt8", 256, 0, 512, (1, 2, 6, 5), False, 8),                      # the 128-cout n-tile, no SiLU
+    ("512_to_128_4chunks", 512, 0, 128, (1, 2, 4, 6), True, None),
+    ("512+256_to_256_6chunks", 512, 256, 256, (1, 2, 5, 5), True, None),          # 64-cout n-tiles
+    ("512+512_to_512_8chunks", 512, 512, 512, (1, 1, 6, 7), True, None),
+    ("128+128_to_128_nt4", 128, 128, 128, (1, 3, 5, 5), True, 4),
+]
+
+
+@pytest.mark.parametrize("name,c1,c2,cout,dims,silu,nt", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
+def test_residual_tail_streaming_kernel(G, monkeypatch, name, c1, c2, cout, dims, silu, nt):
+    """conv1_stream_kernel (csrc/conv1_stream.hip): out = silu?(gn(h) + W [x1 | x2] + b) written over h, against fp32 torch on
+    the same bf16-rounded operands and against the gather kernel's fused tail (models/unet3d.py:102, 112-133)."""
+    E, ctx = G.E, G.ctx()
+    n, d, h, w = dims
+    x1 = bf16_round(formula_input((n, c1, d, h, w), 21))
+    x2 = bf16_round(formula_input((n, c2, d, h, w), 22)) if c2 else None
+    hh = bf16_round(formula_input((n, cout, d, h, w), 23) * 1.5 + 0.25)
+    wt = bf16_round(_w((cout, c1 + c2, 1, 1, 1), 24))
+    bias = formula_input((cout,), 25) * 0.1
+    gnm = torch.nn.GroupNorm(32, cout)
+    with torch.no_grad():
+        gnm.weight.copy_(1 + 0.2 * formula_input((cout,), 26))
+        gnm.bias.copy_(0.1 * formula_input((cout,), 27))
+
+    def run(stream):
+        monkeypatch.setenv("CTSI_CONV1_STREAM", "2" if stream else "0")      # (2: the deep-K forms too, which no plan picks by default)
+        if nt is not None:
+            monkeypatch.setenv("CTSI_CONV1_STREAM_NT", str(nt))
+        with ctx.scope():
+            prog = E.Program(ctx)
+            a1 = G.to_act(prog, x1)
+            a2 = G.to_act(prog, x2) if x2 is not None else None
+            ah = G.to_act(prog, hh)
+            prog.zero_gn_op()
+            slot = prog.gn_finalize(ah, 32, prog.gn_colsum(ah))
+            y, _ = prog.conv("res1x1+gn", lambda: wt, lambda: bias, a1, a2, k=(1, 1, 1), p=(0, 0, 0), cout=cout, out=ah,
+                             fuse_gn=(ah, slot, gnm, silu))
+            kernels = [m[2] for m in prog.op_meta if m[0] == "res1x1+gn"]
+            prog.finalize_layout()
+            prog.run()
+            out = G.from_act(prog, y).cpu()
+        torch.cuda.synchronize()
+        return out, kernels
+
+    out, kernels = run(True)
+    ref = F.group_norm(hh, 32, gnm.weight.detach(), gnm.bias.detach(), 1e-5) + \
+        F.conv3d(torch.cat([x1, x2], 1) if x2 is not None else x1, wt, bias)
+    if silu:
+        ref = F.silu(ref)
+    assert rel_l2(out, ref) < 6e-3, name
+    gather, _ = run(False)
+    assert rel_l2(out, gather) < 6e-3, name                       # (the gather kernel rounds the conv result to bf16 before the add)
+    assert kernels and all(k_.endswith("m10") for k_ in kernels), kernels       # the streaming kernel is what ran
+
+
 def _run_resblock(G, m, x, skip, temb):
     E, ctx = G.E, G.ctx()
     cout = m.conv1.conv.out_channels

@@ -269,6 +269,8 @@ GN_CASES = [
     ("silu_post_only", 64, 8, (1, 2, 6, 6), False, False, True, False, False),
     ("c192_24_chunks_per_row", 192, 8, (1, 3, 6, 7), True, False, False, False, True),
     ("c384_grid_stride", 384, 32, (1, 6, 24, 24), True, False, False, False, False),
+    ("c512_6x6_plane_batch4_small_tiles", 512, 32, (4, 12, 6, 6), True, False, False, False, False),
+    ("c256_12x12_bcast_small_tiles", 256, 32, (2, 8, 12, 12), False, False, False, True, True),
 ]
 
 
@@ -320,6 +322,15 @@ def test_gn_backward_vs_autograd(G, name, c, groups, dims, silu_pre, res, silu_p
                       G._ptr(dtb), c + 3, G._ptr(dxs), cx.sptr)
         dx_f = G.from_act(prog, E.Act(dx, n, c, d, h, w))
         g_f = G.from_act(prog, E.Act(gbuf, n, c, d, h, w))
+        if not res and not silu_post:
+            # without a buffer for the GroupNorm output's gradient pass 3 re-derives it from dy (what the training engine does
+            # wherever nothing else needs that gradient): same dx bit for bit, same parameter gradients
+            dx2, dgam2, dbet2 = torch.empty_like(dx), torch.empty_like(dgam), torch.empty_like(dbet)
+            cx.lib.gn_bwd(ax.ip, ady.ip, int(bcast), C.c_void_p(prog._gn_sums.data_ptr() + slot * 8), G._ptr(gam_d),
+                          G._ptr(bet_d), n, c, d, h, w, groups, 1e-5, int(silu_pre), None, 0, aadd.ip if add else None, None,
+                          G._ptr(dx2), G._ptr(ws), G._ptr(dgam2), G._ptr(dbet2), G._ptr(dtb), c + 3, G._ptr(dxs), cx.sptr)
+            torch.cuda.synchronize()
+            assert torch.equal(dx2.view(torch.int16), dx.view(torch.int16)) and torch.equal(dgam2, dgam) and torch.equal(dbet2, dbet)
     torch.cuda.synchronize()
     want_dx = x.grad + (addt if add else 0.0)
     e_dx = rel_l2(dx_f.cpu(), want_dx)

@@ -745,6 +745,8 @@ struct ctsi_conv_plan {
     int ds;         // halo3 == 7: the strided (3,4,4)/(1,2,2) Downsample form of the k32 kernel (conv3_halo_k32.hip, DS)
     int head2;      // halo3 == 6: conv3_head2_kernel (taps as the GEMM's N dimension) serves the launches that ask for no column sums
     int ksplit;     // halo3 == 7, tile 5: 2 = two blocks per (tile, n-tile), each half of the input-channel chunks (needs a workspace)
+    int stream1;    // > 0: conv1_stream_kernel (conv1_stream.hip: 1x1x1 conv + fused GroupNorm tail as a streaming pass), value = 16-cout
+                    // tiles per n-tile; chosen by ctsi_conv_plan_set_stream_tail, never by ctsi_conv_plan_create
     int halo3;  // 3x3x3 halo-tile kernels: 2 = conv3_halo32_kernel (conv3_halo.hip: 4x2x32 / 4x4x16 / 3x4x16 tiles), 6 = few-cout
                 // heads (conv3_head.hip), 7 = conv3_halo_k32_kernel (conv3_halo_k32.hip: 512- / 384-voxel tiles, ConvTranspose).
                 // 1 (16x16x32 form of the 4x4x16 tile), 3 / 4 (persistent and half-size blocks) and 5 (32x32x16 form of the
@@ -1228,6 +1230,7 @@ extern "C" int ctsi_conv_plan_out_dims(const ctsi_conv_plan* p, int* d, int* h, 
 }
 extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
     if (!p) return 0;
+    if (p->stream1) return (size_t)p->d.cout * p->Cin * 2;
     if (p->halo3 == 6)   // head kernels: conv3_head's image (8 weight rows when cout <= 8; + 1 KB: its last DMA piece is read whole),
         return head1_bytes(p) + (ctsi_conv3_head2_supported(p->Cin, p->d.cout) ? ctsi_conv3_head2_weight_bytes(p->d.cout) : 0);   // then conv3_head2's
     if (p->halo3 == 7) return ctsi_conv3_halo_k32_weight_bytes(p->Cin, p->CoutPad, p->BN, p->ds ? 2 : p->d.transposed);   // entries padded to whole steps
@@ -1251,7 +1254,28 @@ extern "C" int ctsi_conv_plan_config(const ctsi_conv_plan* p, int* bm, int* bn, 
     CTSI_CHECK_ARG(p, "ctsi_conv_plan_config: null plan");
     if (bm) *bm = p->BM;
     if (bn) *bn = p->BN;
-    if (mode) *mode = p->halo3 ? 2 + p->halo3 : (p->small ? 1 : (p->fast ? 2 : 0));
+    if (mode) *mode = p->stream1 ? 10 : (p->halo3 ? 2 + p->halo3 : (p->small ? 1 : (p->fast ? 2 : 0)));
+    if (p->stream1) {
+        if (bm) *bm = 16;
+        if (bn) *bn = p->stream1 * 16;
+    }
+    return CTSI_OK;
+}
+
+// A 1x1x1 stride-1 conv that will run with the fused GroupNorm tail (ctsi_conv_out.gn_x) or as a plain bf16 conv + bias may
+// take the streaming kernel of conv1_stream.hip (another packed-weight layout: call this BEFORE ctsi_conv_plan_weight_bytes /
+// _pack_weights).  on = 1 selects it where the layer qualifies (whole 128-channel chunks per source, cout in whole n-tiles)
+// and is a no-op otherwise -- ctsi_conv_plan_config reports mode 10 when it is active; on = 0 returns to the gather kernel.
+// CTSI_CONV1_STREAM=0 (tuning / test aid) keeps every plan on the gather kernel.
+extern "C" int ctsi_conv_plan_set_stream_tail(ctsi_conv_plan* p, int on) {
+    CTSI_CHECK_ARG(p, "ctsi_conv_plan_set_stream_tail: null plan");
+    p->stream1 = 0;
+    const char* e = getenv("CTSI_CONV1_STREAM");
+    if (!on || (e && atoi(e) == 0)) return CTSI_OK;
+    const ctsi_conv_desc& d = p->d;
+    if (d.transposed || d.kd != 1 || d.kh != 1 || d.kw != 1 || d.sh != 1 || d.sw != 1 || d.pd || d.ph || d.pw || p->dshift)
+        return CTSI_OK;
+    p->stream1 = ctsi_conv1_stream_nt(d.c1, d.c2, d.cout);
     return CTSI_OK;
 }
 
@@ -1266,6 +1290,7 @@ extern "C" int ctsi_conv_plan_set_weight_cin(ctsi_conv_plan* p, int cin_w) {
 extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float* w, void* packed,
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
+    if (p->stream1) return ctsi_conv1_stream_pack(w, packed, p->d.cout, p->Cin, p->CinW, p->stream1, stream);
     if (p->halo3 == 7)
         return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, p->BN, p->ds ? 2 : p->d.transposed, stream);
     if (p->halo3 == 6) {
@@ -1348,6 +1373,34 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
                            o->cout_stride >= o->c_off + p->d.cout,
                        "ctsi_conv_fwd: bf16 output needs cout, cout_stride, c_off multiples of 8 "
                        "(cout=%d stride=%d off=%d)", p->d.cout, o->cout_stride, o->c_off);
+    }
+    if (p->stream1) {
+        CTSI_CHECK_ARG(o->mode == 0 && o->act == 0 && o->colsum == nullptr,
+                       "ctsi_conv_fwd: a streaming 1x1x1 plan writes bf16 without activation or column sums");
+        Conv1StreamParams q;
+        memset(&q, 0, sizeof(q));
+        q.x1 = (const bf16_t*)x1;
+        q.x2 = (const bf16_t*)(x2 ? x2 : x1);
+        q.w = (const bf16_t*)packed_w;
+        q.bias = bias;
+        q.h = (const bf16_t*)o->gn_x;
+        q.y = (bf16_t*)o->y;
+        if (o->gn_x != nullptr) {
+            CTSI_CHECK_ARG(o->gn_sums && o->gn_gamma && o->gn_beta && o->gn_groups > 0 && p->d.cout % o->gn_groups == 0 &&
+                               o->gn_count > 0,
+                           "ctsi_conv_fwd: bad fused GroupNorm arguments (groups=%d, cout=%d)", o->gn_groups, p->d.cout);
+            q.gn_sums = (const double*)o->gn_sums;
+            q.gn_gamma = (const float*)o->gn_gamma;
+            q.gn_beta = (const float*)o->gn_beta;
+            q.gn_groups = o->gn_groups;
+            q.gn_eps = o->gn_eps;
+            q.gn_count = (double)o->gn_count;
+            q.gn_silu = o->gn_silu;
+        }
+        q.C1 = p->d.c1; q.C2 = p->d.c2; q.Cout = p->d.cout;
+        q.cout_stride = o->cout_stride; q.c_off = o->c_off;
+        q.V = (long long)p->Do * p->Ho * p->Wo;
+        return ctsi_conv1_stream_launch(&q, p->d.n, p->stream1, stream);
     }
     if (o->gn_x != nullptr) {
         CTSI_CHECK_ARG(!p->halo3 && o->mode == 0 && o->act == 0 && o->colsum == nullptr && p->nclass == 1,

@@ -166,6 +166,28 @@ extern "C" size_t ctsi_conv3_head2_weight_bytes(int cout);
 extern "C" int ctsi_conv3_head2_pack(const float* w, void* packed, int cout, int cin, int cin_w, void* stream);
 extern "C" int ctsi_conv3_head2_launch(const Conv3HaloParams* hp, int n, const void* packed, int out_mode, int act, long long sn,
                                        long long sc, long long sd, long long sh, long long sw, void* stream);
+// ---- conv1_stream.hip (1x1x1 conv + fused GroupNorm tail, streaming), driven through the conv plan ---------
+struct Conv1StreamParams {
+    const bf16_t* x1;
+    const bf16_t* x2;
+    const bf16_t* w;          // [n-tile][k-step][cout tile t][lane][8 bf16]
+    const float* bias;
+    const bf16_t* h;          // tensor whose GroupNorm is added (may alias y), NULL: plain conv + bias
+    bf16_t* y;
+    const double* gn_sums;
+    const float* gn_gamma;
+    const float* gn_beta;
+    int gn_groups, gn_silu;
+    float gn_eps;
+    double gn_count;
+    int C1, C2, Cout, cout_stride, c_off;
+    long long V;              // voxels per sample
+    int tiles;                // 16-voxel tiles per sample
+    int P;                    // blocks per (sample, n-tile)
+};
+extern "C" int ctsi_conv1_stream_nt(int c1, int c2, int cout);
+extern "C" int ctsi_conv1_stream_pack(const float* w, void* packed, int cout, int cin, int cin_w, int nt, void* stream);
+extern "C" int ctsi_conv1_stream_launch(Conv1StreamParams* q, int n, int nt, void* stream);
 extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad, int bn, int transposed);
 extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w, int bn,
                                         int transposed, void* stream);

@@ -44,7 +44,7 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
                      const double* __restrict__ sums, const float* __restrict__ gamma,
                      const float* __restrict__ beta, int c, long long vox, int groups, float eps,
                      const bf16_t* __restrict__ residual, bf16_t* __restrict__ g_out,
-                     float* __restrict__ colsum3, int tiles) {
+                     float* __restrict__ colsum3, int tiles, int tile_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* s_rs = reinterpret_cast<float*>(smem_raw);   // rstd
     float* s_mr = s_rs + c;                              // -mean*rstd
@@ -69,8 +69,8 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
     const int cpr = c >> 3;
     const int rows_par = 256 / cpr;
     const int q = tid % cpr, rl = tid / cpr;
-    const long long v0 = (long long)tile * GNB_TILE_ROWS;
-    long long v1 = v0 + GNB_TILE_ROWS;
+    const long long v0 = (long long)tile * tile_rows;
+    long long v1 = v0 + tile_rows;
     if (v1 > vox) v1 = vox;
     float a0[8], a1[8], a2[8], a3[8];
 #pragma unroll
@@ -78,7 +78,7 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
     if (rl < rows_par) {
         const bf16_t* xb = x + (long long)nb * vox * c + q * 8;
         const bf16_t* rb = (RES && SILU_POST) ? residual + (long long)nb * vox * c + q * 8 : nullptr;
-        bf16_t* gb = g_out + (long long)nb * vox * c + q * 8;
+        bf16_t* gb = g_out != nullptr ? g_out + (long long)nb * vox * c + q * 8 : nullptr;   // (NULL: pass 3 re-derives g)
         const bf16_t* db = dy + (long long)nb * (dy_mod ? dy_mod : vox) * c + q * 8;
         float rs[8], mr[8], ga[8], be[8];
 #pragma unroll
@@ -125,7 +125,7 @@ gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy
                     a2[k] += gc;
                     a3[k] += xh;
                 }
-                *reinterpret_cast<uint4*>(gb + v * c) = t_pack8(gf);
+                if (gb != nullptr) *reinterpret_cast<uint4*>(gb + v * c) = t_pack8(gf);
             }
         }
 #pragma unroll
@@ -169,7 +169,20 @@ gn_bwd_finalize_kernel(const float* __restrict__ colsum3, const float* __restric
     const float* base = colsum3 + (long long)nb * tiles * 4 * c + c0;
     for (int chl = tid % CB, tl = tid / CB; chl < cn && tl < TL; chl += 256 * ((CB + 255) / 256)) {
         float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
-        for (int t = tl; t < tiles; t += TL) {
+        int t = tl;
+        for (; t + 3 * TL < tiles; t += 4 * TL) {       // 16 independent loads in flight (fixed order: deterministic)
+            float r[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* row = base + (long long)(t + u * TL) * 4 * c + chl;
+                r[u][0] = row[0]; r[u][1] = row[c]; r[u][2] = row[2 * c]; r[u][3] = row[3 * c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                t0 += r[u][0]; t1 += r[u][1]; t2 += r[u][2]; t3 += r[u][3];
+            }
+        }
+        for (; t < tiles; t += TL) {
             const float* row = base + (long long)t * 4 * c + chl;
             t0 += row[0];
             t1 += row[c];
@@ -242,12 +255,15 @@ gn_bwd_param_kernel(const float* __restrict__ pgrad, int n, int c, float* __rest
 
 // Pass 3: dx = rstd*(gamma*g - S1/m - xhat*S2/m) (+ add).  grid (blocks, n), block 256.  The grid stride is a multiple of the
 // row's chunk count (the host picks the block count so), so a thread keeps its 8 channels' five coefficients in registers.
-template <bool ADD>
+// GMODE 0: g is read from pass 1's buffer; 1: g = dy * silu'(gn(x)) re-derived from dy (pass 1 wrote no g: nothing else
+// needs it -- one tensor write less, and pass 3 re-reads what pass 1 just read through the Infinity Cache); 2: g = dy
+// (dy_mod > 0: a depth-broadcast dy).  In modes 1 / 2 `g` is dy.
+template <bool ADD, int GMODE>
 __global__ void __launch_bounds__(256)
 gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, const double* __restrict__ sums,
-                    const float* __restrict__ gamma, const float* __restrict__ s12,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ s12,
                     const bf16_t* __restrict__ add, bf16_t* __restrict__ dx, int c, long long vox, int groups,
-                    float eps, int contig) {
+                    float eps, int contig, long long dy_mod) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* s_rs = reinterpret_cast<float*>(smem_raw);
     float* s_mr = s_rs + c;
@@ -272,7 +288,7 @@ gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, 
     __syncthreads();
     const int cpr = c >> 3;
     const long long total = vox * cpr;
-    const bf16_t* gb = g + (long long)nb * vox * c;
+    const bf16_t* gb = g + (long long)nb * ((GMODE != 0 && dy_mod) ? dy_mod : vox) * c;
     const bf16_t* xb = x + (long long)nb * vox * c;
     const bf16_t* ab = ADD ? add + (long long)nb * vox * c : nullptr;
     bf16_t* ob = dx + (long long)nb * vox * c;
@@ -281,7 +297,12 @@ gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, 
     const long long e0 = (contig ? (long long)blockIdx.x * 512 : (long long)blockIdx.x * 256) + tid;
     const long long total_end = contig && (long long)(blockIdx.x + 1) * 512 < total ? (long long)(blockIdx.x + 1) * 512 : total;
     const int q = (int)(e0 % cpr);                       // stride % cpr == 0: the same chunk every iteration
-    float rs[8], mr[8], ag[8], b1[8], b2[8];
+    float rs[8], mr[8], ag[8], b1[8], b2[8], ga[8], be[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        ga[k] = GMODE == 1 ? gamma[q * 8 + k] : 0.0f;
+        be[k] = GMODE == 1 ? beta[q * 8 + k] : 0.0f;
+    }
 #pragma unroll
     for (int k = 0; k < 8; k += 4) {
         *reinterpret_cast<float4*>(rs + k) = *reinterpret_cast<const float4*>(s_rs + q * 8 + k);
@@ -298,7 +319,9 @@ gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float xh = xf[k] * rs[k] + mr[k];
-            float v = ag[k] * gf[k] - b1[k] - xh * b2[k];
+            float gg = gf[k];
+            if (GMODE == 1) gg = bf16_to_f32(f32_to_bf16(gg * silu_grad_f(xh * ga[k] + be[k])));   // (rounded as pass 1's buffer was)
+            float v = ag[k] * gg - b1[k] - xh * b2[k];
             if (ADD) v += af[k];
             of[k] = v;
         }
@@ -310,21 +333,35 @@ gn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, 
         uint4 gr[U], xr[U], ar[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            gr[u] = *reinterpret_cast<const uint4*>(gb + (e + u * stride) * 8);
+            const long long eg = (GMODE != 0 && dy_mod) ? ((e + u * stride) / cpr % dy_mod) * cpr + q : e + u * stride;
+            gr[u] = *reinterpret_cast<const uint4*>(gb + eg * 8);
             xr[u] = *reinterpret_cast<const uint4*>(xb + (e + u * stride) * 8);
             ar[u] = ADD ? *reinterpret_cast<const uint4*>(ab + (e + u * stride) * 8) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) one(gr[u], xr[u], ar[u], e + u * stride);
     }
-    for (; e < total_end; e += stride)
-        one(*reinterpret_cast<const uint4*>(gb + e * 8), *reinterpret_cast<const uint4*>(xb + e * 8),
+    for (; e < total_end; e += stride) {
+        const long long eg = (GMODE != 0 && dy_mod) ? (e / cpr % dy_mod) * cpr + q : e;
+        one(*reinterpret_cast<const uint4*>(gb + eg * 8), *reinterpret_cast<const uint4*>(xb + e * 8),
             ADD ? *reinterpret_cast<const uint4*>(ab + e * 8) : make_uint4(0, 0, 0, 0), e);
+    }
 }
 
-extern "C" int ctsi_gn_bwd_tiles(int d, int h, int w) {
+extern "C" int ctsi_gn_bwd_tiles(int d, int h, int w) {      // (tiles at the full 512-row tile; see gnb_tile_rows)
     const long long vox = (long long)d * h * w;
     return (int)((vox + GNB_TILE_ROWS - 1) / GNB_TILE_ROWS);
+}
+
+// Rows per tile of pass 1: 512 for large tensors; halved until the launch has ~2048 blocks, down to one batch of four rows per
+// thread lane.  With fixed 512-row tiles the coarse levels of a 192^2 patch were 16-216 blocks whose threads walked 32-128
+// voxels one load batch after the other: 38-47 us per launch whatever the tensor size (profiles/r03_train_kernel_stats.csv).
+static int gnb_tile_rows(int n, int c, long long vox) {
+    const int rows_par = 256 / (c >> 3);
+    const int min_rows = rows_par * 4 > 16 ? rows_par * 4 : 16;
+    int rows = GNB_TILE_ROWS;
+    while (rows > min_rows && (long long)n * ((vox + rows - 1) / rows) < 2048) rows >>= 1;
+    return rows;
 }
 
 extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const double* sums, const float* gamma,
@@ -332,12 +369,15 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
                            const void* residual, int silu_post, const void* add, void* g_buf, void* dx,
                            float* workspace, float* dgamma, float* dbeta, float* dtbias, long long dtbias_stride,
                            float* dxsum, void* stream) {
-    CTSI_CHECK_ARG(x && dy && sums && gamma && beta && g_buf && dx && workspace && dgamma && dbeta,
+    CTSI_CHECK_ARG(x && dy && sums && gamma && beta && dx && workspace && dgamma && dbeta,
                    "ctsi_gn_bwd: null argument");
+    // g_buf may be NULL when nothing but pass 3 needs the GroupNorm output's gradient: pass 3 re-derives it from dy
+    CTSI_CHECK_ARG(g_buf || (!residual && !silu_post), "ctsi_gn_bwd: g_buf may only be omitted without residual / post-SiLU");
     CTSI_CHECK_ARG(c % 8 == 0 && c <= 2048 && groups > 0 && c % groups == 0, "ctsi_gn_bwd: bad c=%d groups=%d", c,
                    groups);
     const long long vox = (long long)d * h * w;
-    const int tiles = ctsi_gn_bwd_tiles(d, h, w);
+    const int tile_rows = gnb_tile_rows(n, c, vox);
+    const int tiles = (int)((vox + tile_rows - 1) / tile_rows);
     hipStream_t st = (hipStream_t)stream;
     // workspace: colsum3 [n][tiles][4][c] | s12 [n][groups][2] | pgrad [n][4][c]
     float* colsum3 = workspace;
@@ -349,7 +389,7 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
     const size_t lds1 = (size_t)(4 * c + rows_par * 4 * c) * sizeof(float);
     CTSI_CHECK_ARG(lds1 <= 160 * 1024, "ctsi_gn_bwd: LDS budget exceeded for c=%d", c);
     typedef void (*reduce_fn)(const bf16_t*, const bf16_t*, long long, const double*, const float*, const float*, int, long long,
-                              int, float, const bf16_t*, bf16_t*, float*, int);
+                              int, float, const bf16_t*, bf16_t*, float*, int, int);
     static const reduce_fn reduce_tab[8] = {
         gn_bwd_reduce_kernel<false, false, false>, gn_bwd_reduce_kernel<true, false, false>,
         gn_bwd_reduce_kernel<false, true, false>,  gn_bwd_reduce_kernel<true, true, false>,
@@ -361,7 +401,7 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     hipLaunchKernelGGL(reduce, dim3(tiles, n), dim3(256), lds1, st, (const bf16_t*)x, (const bf16_t*)dy,
                        dy_bcast_d ? (long long)h * w : 0ll, sums, gamma, beta, c, vox, groups, eps,
-                       (const bf16_t*)residual, (bf16_t*)g_buf, colsum3, tiles);
+                       (const bf16_t*)residual, (bf16_t*)g_buf, colsum3, tiles, tile_rows);
     CTSI_LAUNCH_CHECK();
     {
         const int cpg = c / groups;
@@ -391,20 +431,26 @@ extern "C" int ctsi_gn_bwd(const void* x, const void* dy, int dy_bcast_d, const 
         const int need = cpr / gq;
         blocks = (blocks + need - 1) / need * need;
     }
-    if (add)
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)blocks, n), dim3(256), 5 * c * sizeof(float), st,
-                           (const bf16_t*)g_buf, (const bf16_t*)x, sums, gamma, s12, (const bf16_t*)add, (bf16_t*)dx, c, vox,
-                           groups, eps, contig);
-    else
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3((unsigned)blocks, n), dim3(256), 5 * c * sizeof(float), st,
-                           (const bf16_t*)g_buf, (const bf16_t*)x, sums, gamma, s12, (const bf16_t*)add, (bf16_t*)dx, c, vox,
-                           groups, eps, contig);
+    {
+        typedef void (*apply_fn)(const bf16_t*, const bf16_t*, const double*, const float*, const float*, const float*,
+                                 const bf16_t*, bf16_t*, int, long long, int, float, int, long long);
+        static const apply_fn apply_tab[6] = {gn_bwd_apply_kernel<false, 0>, gn_bwd_apply_kernel<true, 0>,
+                                              gn_bwd_apply_kernel<false, 1>, gn_bwd_apply_kernel<true, 1>,
+                                              gn_bwd_apply_kernel<false, 2>, gn_bwd_apply_kernel<true, 2>};
+        const int gmode = g_buf ? 0 : (silu_pre ? 1 : 2);
+        const long long dy_mod = (gmode != 0 && dy_bcast_d) ? (long long)h * w : 0ll;
+        hipLaunchKernelGGL(apply_tab[gmode * 2 + (add ? 1 : 0)], dim3((unsigned)blocks, n), dim3(256), 5 * c * sizeof(float), st,
+                           (const bf16_t*)(g_buf ? g_buf : dy), (const bf16_t*)x, sums, gamma, beta, s12, (const bf16_t*)add,
+                           (bf16_t*)dx, c, vox, groups, eps, contig, dy_mod);
+    }
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
 }
 
 extern "C" size_t ctsi_gn_bwd_workspace_floats(int n, int c, int d, int h, int w, int groups) {
-    const long long tiles = ctsi_gn_bwd_tiles(d, h, w);
+    const long long vox = (long long)d * h * w;
+    const int tile_rows = gnb_tile_rows(n, c, vox);
+    const long long tiles = (vox + tile_rows - 1) / tile_rows;
     return (size_t)((long long)n * tiles * 4 * c + (long long)n * groups * 2 + (long long)n * 4 * c);
 }
 

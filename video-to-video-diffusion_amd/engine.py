@@ -515,6 +515,9 @@ class Program:
         self.plans.append(plan)
         if cin_w is not None:
             lib.conv_plan_set_weight_cin(plan, cin_w)
+        if fuse_gn is not None and tuple(k) == (1, 1, 1) and f32_out is None and not want_stats and act == 0:
+            # the ResBlock tails are HBM-bound passes: the streaming kernel where the layer qualifies (csrc/conv1_stream.hip)
+            lib.conv_plan_set_stream_tail(plan, 1)
         if norm_in is not None:
             nslot, ngn, nsilu, ntb = norm_in      # normalise in place, then a plain conv
             kw_tb = {} if ntb is None else dict(tbias=ntb[0], tbias_off=ntb[1], tbias_stride=ntb[2], step_ptr=ntb[3])
@@ -531,7 +534,7 @@ class Program:
         lib.conv_plan_config(plan, C.byref(bm), C.byref(bn), C.byref(mode))
         layout = "gather" if mode.value in (0, 2) else mode.value      # the packed image depends on the kernel family,
         sig = (layout, int(transposed), tuple(k), tuple(s), x1.c, 0 if x2 is None else x2.c, cout, cin_w,   # not the shape
-               lib.conv_plan_cout_pad(plan), wbytes)
+               lib.conv_plan_cout_pad(plan), wbytes, bn.value)
         holder: List[Optional[torch.Tensor]] = [None]
         prog = self
 

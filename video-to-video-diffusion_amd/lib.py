@@ -78,6 +78,7 @@ SIGNATURES = {
     "ctsi_ndhwc_f32_to_ncdhw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp], True),
     "ctsi_conv_plan_create": (_i, [C.POINTER(_vp), C.POINTER(ConvDesc)], True),
     "ctsi_conv_plan_set_weight_cin": (_i, [_vp, _i], True),
+    "ctsi_conv_plan_set_stream_tail": (_i, [_vp, _i], True),
     "ctsi_conv_plan_destroy": (None, [_vp], False),
     "ctsi_conv_plan_out_dims": (_i, [_vp, _ip, _ip, _ip], True),
     "ctsi_conv_plan_weight_bytes": (_sz, [_vp], False),

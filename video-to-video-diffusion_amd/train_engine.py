@@ -341,6 +341,9 @@ class UNetTrainProgram(Program):
             residual.grad = self.act_like(residual)
             gbuf = residual.grad
             add_to_res = False
+        elif residual is None and not silu_post:
+            gbuf = None         # nobody but pass 3 needs the GroupNorm output's gradient: it re-derives it from dy (no buffer, no write)
+            add_to_res = False
         else:
             tmp = self.act_like(x)
             gbuf = tmp
@@ -351,7 +354,7 @@ class UNetTrainProgram(Program):
         xp, gyp, gp, bp = x.ip, gy.ip, _ptr(gamma), _ptr(beta)
         rp = C.c_void_p(0) if residual is None else residual.ip
         ap = C.c_void_p(0) if add is None else add.ip
-        gbp, dxp, dgp, dbp = gbuf.ip, x.grad.ip, _ptr(dgam), _ptr(dbet)
+        gbp, dxp, dgp, dbp = (C.c_void_p(0) if gbuf is None else gbuf.ip), x.grad.ip, _ptr(dgam), _ptr(dbet)
         dtp = C.c_void_p(0 if tb_off is None else self.d_tbias.data_ptr() + 4 * tb_off)
         tstride = self.total_out
         dxsp = _ptr(dxsum)

@@ -268,7 +268,9 @@ typedef struct ctsi_wgrad_desc {
 } ctsi_wgrad_desc;
 size_t ctsi_wgrad_workspace_bytes(const ctsi_wgrad_desc* desc);
 double ctsi_wgrad_flops(const ctsi_wgrad_desc* desc);
-int ctsi_wgrad(const ctsi_wgrad_desc* desc, const void* r, const void* g, void* workspace, float* dw,
+/* workspace_bytes: size of `workspace`; the call fails (nothing is launched) when it is smaller than what
+ * ctsi_wgrad_workspace_bytes(desc) returns at launch time */
+int ctsi_wgrad(const ctsi_wgrad_desc* desc, const void* r, const void* g, void* workspace, size_t workspace_bytes, float* dw,
                long long stride_r, long long stride_g, long long stride_t, float scale, void* stream);
 
 /* out (ci_cnt, cout, T) with out[ci'][co][T-1-t] = w[co][ci_off+ci'][t]: the weight of the stride-1 'same' Conv3d

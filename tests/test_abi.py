@@ -127,7 +127,7 @@ def test_training_and_next_row_entry_points_validate_arguments(lib):
     assert lib.wgrad_workspace_bytes(C.byref(bad)) == 0 and lib.wgrad_flops(C.byref(bad)) == 0.0
     one = C.c_void_p(16)   # never dereferenced: every call below fails its argument check first
     with pytest.raises(L.CtsiError, match="multiples of 8"):
-        lib.wgrad(C.byref(bad), one, one, one, one, 1, 1, 1, 1.0, None)
+        lib.wgrad(C.byref(bad), one, one, one, 1 << 30, one, 1, 1, 1, 1.0, None)
     with pytest.raises(L.CtsiError, match="outside the volume"):
         lib.blend_accumulate(one, one, one, one, one, one, 1, 4, 16, 16, 6, 24, 24, 3, 0, 0, None)
     with pytest.raises(L.CtsiError, match="window must be odd"):
@@ -140,5 +140,8 @@ def test_training_and_next_row_entry_points_validate_arguments(lib):
     with pytest.raises(L.CtsiError, match="bad arguments"):
         lib.q_sample(one, one, one, one, one, one, 1, 8, 2, 2, 2, 8, 4, None)   # channel slice exceeds c_total
     assert lib.gn_bwd_tiles(48, 48, 48) == 48 ** 3 // 512
-    assert lib.gn_bwd_workspace_floats(4, 128, 48, 48, 48, 8) == 4 * 216 * 4 * 128 + 4 * 8 * 2 + 4 * 4 * 128
+    # (the statistics tile halves from 512 rows until the launch has ~2048 blocks: 128 rows -> 864 tiles per sample here;
+    #  a 3.2 GB tensor keeps the 512-row tile)
+    assert lib.gn_bwd_workspace_floats(4, 128, 48, 48, 48, 8) == 4 * 864 * 4 * 128 + 4 * 8 * 2 + 4 * 4 * 128
+    assert lib.gn_bwd_workspace_floats(1, 128, 48, 512, 512, 8) == 24576 * 4 * 128 + 8 * 2 + 4 * 128
     assert lib.slice_metrics_workspace_doubles(1, 1, 48, 512, 512) == 48 * 32 * 32 * 4

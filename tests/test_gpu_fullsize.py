@@ -250,6 +250,49 @@ def test_generate_config1(full_model):
     _free()
 
 
+def test_ddpm_config1_prefix_and_full_1000_steps(full_model):
+    """DDPM at a real size (models/diffusion.py:340-367, inference/sampler.py:35-61): the full 264.66 M-param model on the
+    config-1 latent (1,8,48,48,48).  (i) the first 30 ancestral steps (t = 999 .. 970) with injected noise, every step against
+    the fp32 oracle under the same yardstick as the DDIM trajectories: the oracle under bf16 autocast on this device;
+    (ii) all 1000 steps through generate(): finite, in range, wall-clock printed (the reference's README quotes ~10 min)."""
+    import time
+    model, sd = full_model
+    shape = (1, 8, 48, 48, 48)
+    g = torch.Generator().manual_seed(3)
+    cond = torch.randn(shape, generator=g).to(DEV)
+    pkg_ = importlib.import_module("video-to-video-diffusion_amd")
+    traj = []
+    pkg_.DDPMSampler(model.diffusion, model.unet).sample(shape, cond, DEV, progress=False, noise_fn=_noise_fn, num_steps=30,
+                                                         trajectory=traj)
+    usd = {k[len("unet."):]: v for k, v in sd.items() if k.startswith("unet.")}
+    ref_model = lambda z, t, c: R.unet_forward(usd, UNET_CFG, z, t, c)
+    bufs = {k: v.to(DEV) for k, v in R.diffusion_buffers("cosine", 1000).items()}
+    with torch.no_grad():
+        tr_ref, tr_bf = [], []
+        R.ddpm_sample(ref_model, bufs, shape, cond, noise_fn=_noise_fn, num_steps=30, trajectory=tr_ref)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            R.ddpm_sample(ref_model, bufs, shape, cond, noise_fn=_noise_fn, num_steps=30, trajectory=tr_bf)
+    errs = [rel_l2(traj[i], tr_ref[i]) for i in range(30)]
+    errs_b = [rel_l2(tr_bf[i].float(), tr_ref[i]) for i in range(30)]
+    print("DDPM config 1, per-step rel-L2 hip     ", ["%.3g" % e for e in errs])
+    print("                              autocast ", ["%.3g" % e for e in errs_b])
+    for i in range(30):
+        assert errs[i] <= 1.0116 * errs_b[i] + 1e-3, (i, errs[i], errs_b[i])
+    del tr_ref, tr_bf, traj
+    _free()
+    v_in = (torch.rand((1, 1, 8, 192, 192), generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = model.generate(v_in, 'ddpm', target_depth=48)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(f"generate(sampler='ddpm'), 1000 steps, 8 -> 48 slices @192x192: {dt:.2f} s warm")
+    assert tuple(out.shape) == (1, 1, 48, 192, 192) and torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6
+    model.invalidate_engine_cache()
+    _free()
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # (e) one config-3 training micro-step: B = 4 patches of 192x192, 8 -> 48 slices, loss + gradients vs the oracle's autograd
 # --------------------------------------------------------------------------------------------------------------------

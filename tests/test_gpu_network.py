@@ -450,7 +450,7 @@ def test_stitching_window_batching_keeps_the_rng_stream(pkg):
     v_full = formula_input((1, 1, 6, 40, 24), 17).clamp(-1, 1).to(DEV)
     sampler = pkg.DDIMSampler(model.diffusion, model.unet)
     outs = []
-    for wb in (1, 4, 3):
+    for wb in (1, 4, 3, None):       # None = the default: every window the device memory holds, here all of them at once
         torch.manual_seed(123)
         outs.append(sampler.sample_with_stitching(v_full, model.vae, 3, patch_size=(4, 16, 16),
                                                   target_patch_size=(4, 16, 16), stride=(2, 8, 8), device=DEV,

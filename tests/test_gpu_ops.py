@@ -160,6 +160,77 @@ def test_conv3_halo_tile_kernel(G, monkeypatch, name, c1, c2, cout, dims, tile):
     assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
 
 
+NARROW_CASES = [
+    # name, c1, c2, cout, (n, d, h, w), expected tile rows (BM)
+    ("w24_256_256_ragged_depth", 256, 0, 256, (2, 6, 8, 24), 384),           # 4x4x24 tile; depth 6 = 1.5 tiles
+    ("w24_concat_128+64_cout128", 128, 64, 128, (1, 8, 12, 24), 384),
+    ("w48_two_tiles_per_line", 64, 0, 128, (1, 4, 4, 48), None),             # 48 = 3 x 16: stays on a 16-wide tile
+    ("w12_512_512", 512, 0, 512, (2, 16, 12, 12), 384),                      # 8x4x12 tile
+    ("w12_ragged_h_and_d", 64, 0, 64, (1, 11, 10, 12), 384),
+    ("w36_three_tiles_of_12", 32, 32, 72, (1, 8, 4, 36), 384),
+]
+
+
+@pytest.mark.parametrize("name,c1,c2,cout,dims,bm", NARROW_CASES, ids=[c[0] for c in NARROW_CASES])
+def test_conv3_halo_k32_narrow_plane_tiles(G, monkeypatch, name, c1, c2, cout, dims, bm):
+    """The k32 kernel's 4x4x24 / 8x4x12 tiles (A tiles that straddle W-lines) on the 24- and 12-wide planes of 192^2 patches:
+    against fp32 torch, with the GroupNorm column sums, and against the tile the plan would take without them."""
+    n, d, h, w = dims
+    x1 = bf16_round(formula_input((n, c1, d, h, w), 1))
+    x2 = bf16_round(formula_input((n, c2, d, h, w), 2)) if c2 else None
+    x = torch.cat([x1, x2], 1) if c2 else x1
+    wt = bf16_round(_w((cout, c1 + c2, 3, 3, 3), 3))
+    b = formula_input((cout,), 4) * 0.1
+    ref = F.conv3d(x, wt, b, padding=1)
+    groups = 8
+    monkeypatch.setenv("CTSI_CONV_K32_NARROW", "1")          # wherever the plane divides (the small test grids have < 200 blocks)
+    if bm is not None:
+        L = importlib.import_module("video-to-video-diffusion_amd.lib")
+        import ctypes as C
+        lib = L.get_lib()
+        desc = L.ConvDesc(0, 3, 3, 3, 1, 1, 1, 1, 1, n, c1, c2, cout, d, h, w, 0)
+        plan = C.c_void_p()
+        lib.conv_plan_create(C.byref(plan), C.byref(desc))
+        pbm, pbn, mode = C.c_int(), C.c_int(), C.c_int()
+        lib.conv_plan_config(plan, C.byref(pbm), C.byref(pbn), C.byref(mode))
+        lib.conv_plan_destroy(plan)
+        assert (pbm.value, mode.value) == (bm, 9), (pbm.value, mode.value)
+    y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=groups)
+    assert rel_l2(y, ref) < CONV_TOL, name
+    rg = ref.reshape(n, groups, -1).double()
+    assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+    assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
+    monkeypatch.setenv("CTSI_CONV_K32_NARROW", "0")
+    y2, _ = G.run_conv(x1, x2, wt, b)
+    assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("kind,cin,cout,dims", [("up", 128, 128, (1, 8, 8, 24)), ("up", 256, 128, (2, 16, 8, 12)),
+                                                ("down", 128, 128, (1, 8, 16, 48)), ("down", 64, 192, (2, 16, 8, 24))],
+                         ids=["convT_in24", "convT_in12_batch2", "down_out24", "down_out12_batch2"])
+def test_narrow_plane_tiles_transposed_and_strided_forms(G, monkeypatch, kind, cin, cout, dims):
+    """ConvTranspose3d / strided Conv3d (3,4,4)/(1,2,2) on the 4x4x24 / 8x4x12 tiles of the k32 kernel (opt-in:
+    CTSI_CONV_K32_NARROW_TD), against fp32 torch and against the 16-wide tiles."""
+    n, d, h, w = dims
+    x = bf16_round(formula_input((n, cin, d, h, w), 1))
+    b = formula_input((cout,), 4) * 0.1
+    if kind == "up":
+        wt = bf16_round(_w((cin, cout, 3, 4, 4), 5, transposed=True))
+        ref = F.conv_transpose3d(x, wt, b, stride=(1, 2, 2), padding=(1, 1, 1))
+        kw = dict(transposed=True, k=(3, 4, 4), s=(2, 2))
+    else:
+        wt = bf16_round(_w((cout, cin, 3, 4, 4), 5))
+        ref = F.conv3d(x, wt, b, stride=(1, 2, 2), padding=(1, 1, 1))
+        kw = dict(k=(3, 4, 4), s=(2, 2))
+    monkeypatch.setenv("CTSI_CONV_K32_NARROW_TD", "1")
+    monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
+    y, _ = G.run_conv(x, None, wt, b, **kw)
+    assert rel_l2(y, ref) < CONV_TOL
+    monkeypatch.delenv("CTSI_CONV_K32_NARROW_TD")
+    y2, _ = G.run_conv(x, None, wt, b, **kw)
+    assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
 DOWN_CASES = [
     # name, cin, cout, (n, d, h_in, w_in)
     ("aligned_128_128", 128, 128, (1, 4, 8, 64)),

@@ -46,7 +46,7 @@ def _wgrad(G, r, g, k, s, p, n_taps_shape, out_shape, stride_rgt, c_off_elems=0,
         ws = torch.empty(max(c.lib.wgrad_workspace_bytes(C.byref(desc)), 16), dtype=torch.uint8, device=DEV)
         if dw is None:
             dw = torch.full(out_shape, float("nan"), dtype=torch.float32, device=DEV)
-        c.lib.wgrad(C.byref(desc), ar.ip, ag.ip, G._ptr(ws), C.c_void_p(dw.data_ptr() + 4 * c_off_elems), stride_rgt[0],
+        c.lib.wgrad(C.byref(desc), ar.ip, ag.ip, G._ptr(ws), ws.numel(), C.c_void_p(dw.data_ptr() + 4 * c_off_elems), stride_rgt[0],
                     stride_rgt[1], stride_rgt[2], 1.0, c.sptr)
     torch.cuda.synchronize()
     return dw

@@ -6,7 +6,7 @@ O=gpurun_out/r4
 mkdir -p $O
 C=${CTSI_COMMIT:-unknown}   # git is not available on the GPU box: pass the short hash
 # 1. the bench command under rocprofv3 --kernel-trace --stats (same command as the bench log next to it)
-python3 bench.py --steps 20 --warmup 5 > $O/bench_v3.log 2>&1
+python3 bench.py --steps 20 --warmup 5 > $O/bench_ev.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-volume > $O/prof_bench.log 2>&1
 # 2. PMC traffic (separate passes) + MFMA busy / LDS conflicts over the eager U-Net evaluations
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o fetch -- python3 tools/profile_ops.py --repeats 1 > $O/pmc_fetch.log 2>&1

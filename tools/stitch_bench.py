@@ -10,7 +10,7 @@ torch.manual_seed(0)
 model = pkg.VideoToVideoDiffusion(bench.EFFECTIVE_CFG).eval().to(dev)
 sampler = pkg.DDIMSampler(model.diffusion, model.unet)
 v = (torch.rand(1, 1, 8, 512, 512) * 2 - 1).to(dev)
-for wb in [int(x) for x in (sys.argv[1:] or ["1", "4", "5"])]:
+for wb in [int(x) for x in (sys.argv[1:] or ["1", "5", "8", "13", "0"])]:      # 0 = automatic (all windows that fit)
     for rep in range(2):
         torch.manual_seed(1)
         torch.cuda.synchronize()

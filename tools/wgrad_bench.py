@@ -31,10 +31,10 @@ for name, cg, cr, (n, d, h, w), k in SHAPES:
     with ctx.scope():
         e0, e1 = C.c_void_p(), C.c_void_p()
         lib.event_create(C.byref(e0)); lib.event_create(C.byref(e1))
-        lib.wgrad(C.byref(desc), E._ptr(r), E._ptr(g), E._ptr(ws), E._ptr(dw), cg * T, T, 1, 1.0, ctx.sptr)
+        lib.wgrad(C.byref(desc), E._ptr(r), E._ptr(g), E._ptr(ws), ws.numel() * ws.element_size(), E._ptr(dw), cg * T, T, 1, 1.0, ctx.sptr)
         lib.event_record(e0, ctx.sptr)
         for _ in range(a.reps):
-            lib.wgrad(C.byref(desc), E._ptr(r), E._ptr(g), E._ptr(ws), E._ptr(dw), cg * T, T, 1, 1.0, ctx.sptr)
+            lib.wgrad(C.byref(desc), E._ptr(r), E._ptr(g), E._ptr(ws), ws.numel() * ws.element_size(), E._ptr(dw), cg * T, T, 1, 1.0, ctx.sptr)
         lib.event_record(e1, ctx.sptr)
     torch.cuda.synchronize()
     ms = C.c_float()

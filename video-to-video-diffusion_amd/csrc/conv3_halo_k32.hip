@@ -61,7 +61,11 @@ struct HkCfg {
     static constexpr int OFF_CS = OFF_ROW + BM * 8;
     static constexpr int LDS_BYTES = OFF_CS + NWAVE * BN * 8;
     static constexpr int LPW = 64 / TW;                     // W-lines per wave
-    static_assert(BM % 128 == 0 && (MA == 3 || (MA == 4 && TH % LPW == 0)) && NPIECE <= 5 && LDS_BYTES <= 160 * 1024 &&
+    // TW = 24 / 12 (round 4: the 24- and 12-wide planes of 192^2 patches, which 16- / 32-wide tiles cover at 75 %): a 16-row A tile
+    // then STRADDLES W-lines, so every lane carries its own row offset per A tile instead of one wave-uniform offset (MA more
+    // v_add per unit); nothing else in the kernel assumes that an A tile lies in one line
+    static constexpr bool STRADDLE = TW % 16 != 0;
+    static_assert(BM % 128 == 0 && (MA == 3 || (MA == 4 && TH % LPW == 0 && !STRADDLE)) && NPIECE <= 5 && LDS_BYTES <= 160 * 1024 &&
                       WSLOT_BYTES == 16384 && (UPS == 2 || UPS == 4), "unsupported tile");
     // A tile i (rows [16 i, 16 i + 16) of the wave's 64): halo-voxel offset from the wave's first voxel
     static constexpr int a_imm(int i) { return (((16 * i) / TW) * HW + (16 * i) % TW) * 32; }
@@ -286,14 +290,21 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         };
         const int row0 = wave * 16 * MA;
         const int vbase = hv(row0);
+        if constexpr (Cfg::STRADDLE) {                       // per-lane offsets: row r16 of A tile i may lie on the next W-line
+            const int v0 = hv(row0 + r16);
 #pragma unroll
-        for (int i = 0; i < MA; ++i) {
-            if constexpr (MA == 4)
-                aoff[i] = Cfg::a_imm(i);
-            else
-                aoff[i] = (hv(row0 + 16 * i) - vbase) * 32;
+            for (int i = 0; i < MA; ++i) aoff[i] = (hv(row0 + 16 * i + r16) - v0) * 32;
+            a_lane = v0 * 32 + (kg & 1) * 16;
+        } else {
+#pragma unroll
+            for (int i = 0; i < MA; ++i) {
+                if constexpr (MA == 4)
+                    aoff[i] = Cfg::a_imm(i);
+                else
+                    aoff[i] = (hv(row0 + 16 * i) - vbase) * 32;
+            }
+            a_lane = (vbase + r16) * 32 + (kg & 1) * 16;
         }
-        a_lane = (vbase + r16) * 32 + (kg & 1) * 16;
         b_lane = OFF_W + (kg >> 1) * TAP_BYTES + r16 * 32 + (kg & 1) * 16;
     }
     // LDS byte offset of entry q's tap in its halo buffer (wave-uniform); entries past the end repeat the last one (their
@@ -744,9 +755,32 @@ extern "C" size_t ctsi_conv3_halo_k32_splitk_bytes(int tiles) {   // [2 ints per
     return sync + (size_t)tiles * (4 * 8 * 4) * 512 * sizeof(float);   // sized for the 512-voxel tile (128 accumulators per lane)
 }
 
-extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16, 3: 3x4x32, 5: 3x8x16 */, int bn,
-                                          void* stream) {
-    CTSI_CHECK_ARG(bn == 128 && (tile == 0 || tile == 2 || tile == 3 || tile == 5), "ctsi_conv3_halo_k32_launch: bad BN %d / tile %d", bn, tile);
+extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /* 0: 4x4x32, 2: 4x8x16, 3: 3x4x32, 5: 3x8x16, 6: 4x4x24, 7: 8x4x12 */,
+                                          int bn, void* stream) {
+    CTSI_CHECK_ARG(bn == 128 && (tile == 0 || tile == 2 || tile == 3 || tile == 5 || tile == 6 || tile == 7),
+                   "ctsi_conv3_halo_k32_launch: bad BN %d / tile %d", bn, tile);
+    if (tile == 6 || tile == 7) {   // 384-voxel tiles for 24- / 12-wide planes (no split-K form)
+        CTSI_CHECK_ARG(hp->ksplit != 2 && !(hp->ds && hp->tr), "ctsi_conv3_halo_k32_launch: tile %d has no split-K form", tile);
+        if (hp->ds) {
+            CTSI_CHECK_ARG(hp->Hi == 2 * hp->Ho && hp->Wi == 2 * hp->Wo && hp->C2 == 0 && hp->nchunks % 4 == 0,
+                           "ctsi_conv3_halo_k32_launch: the Downsample form needs even input planes and one source");
+            if (tile == 6)
+                hk_launch<4, 4, 24, 128, 2, false, false, true>(hp, (hipStream_t)stream);
+            else
+                hk_launch<8, 4, 12, 128, 2, false, false, true>(hp, (hipStream_t)stream);
+        } else if (hp->tr) {
+            if (tile == 6)
+                hk_launch<4, 4, 24, 128, 2, true>(hp, (hipStream_t)stream);
+            else
+                hk_launch<8, 4, 12, 128, 2, true>(hp, (hipStream_t)stream);
+        } else if (tile == 6) {
+            hk_launch<4, 4, 24, 128, 2, false>(hp, (hipStream_t)stream);
+        } else {
+            hk_launch<8, 4, 12, 128, 2, false>(hp, (hipStream_t)stream);
+        }
+        CTSI_LAUNCH_CHECK();
+        return CTSI_OK;
+    }
     if (hp->ds) {   // strided Conv3d (3,4,4)/(1,2,2): nchunks counts virtual chunks (4 per 16 input channels)
         CTSI_CHECK_ARG(!hp->tr && hp->Hi == 2 * hp->Ho && hp->Wi == 2 * hp->Wo && hp->C2 == 0 && hp->nchunks % 4 == 0,
                        "ctsi_conv3_halo_k32_launch: the Downsample form needs even input planes and one source");

@@ -740,7 +740,7 @@ struct ctsi_conv_plan {
     int tap_margin[4], ad_min[4];
     int fast, dshift;
     int h32_w16;    // halo3 == 2 only: 1 = 4x4x16 tile (two W-lines of 16 per A tile), 2 = 3x4x16 tile, instead of 4x2x32
-    int m512_w16;   // halo3 == 7 only: tile of the k32 kernel: 0 = 4x4x32, 2 = 4x8x16, 3 = 3x4x32, 5 = 3x8x16 (384 voxels)
+    int m512_w16;   // halo3 == 7 only: tile of the k32 kernel: 0 = 4x4x32, 2 = 4x8x16, 3 = 3x4x32, 5 = 3x8x16, 6 = 4x4x24, 7 = 8x4x12 (384 voxels)
     int gsplit;     // gather kernel (halo3 == 0): S-way split-K for launches of a few dozen blocks with a deep K loop (needs a workspace)
     int ds;         // halo3 == 7: the strided (3,4,4)/(1,2,2) Downsample form of the k32 kernel (conv3_halo_k32.hip, DS)
     int head2;      // halo3 == 6: conv3_head2_kernel (taps as the GEMM's N dimension) serves the launches that ask for no column sums
@@ -1049,17 +1049,59 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 }
             }
         }
+        if (k3 && (c32 || c16) && d.cout >= 64 && d.cout % 8 == 0 && p->CinW == p->Cin && extent < 2.0e9 && !getenv("CTSI_CONV_NO_HALO3")) {
+            // 24- and 12-wide planes (the 48 x 24^2 / 48 x 12^2 levels of 192^2 patches: config 1, config 3, stitching windows): 16- and
+            // 32-wide tiles cover them at 75 %.  The k32 kernel's 384-voxel tiles 4x4x24 / 8x4x12 (A tiles that straddle W-lines,
+            // conv3_halo_k32.hip) cover them whole.  Same score as above (useful rows x fill of the 256 CUs x relative efficiency);
+            // taken only when clearly ahead: 25 stitching windows at once 113 -> 101 ms per U-Net evaluation (L1 + L2 convs 57.9 ->
+            // 46.2 ms), while at B = 4 (config 3) the fewer, larger tiles fill the CUs worse (L2: 288 blocks = 1.1 rounds) and
+            // the 16-wide tiles stay (measured equal / slower: profiles/r04_notes.md).  CTSI_CONV_K32_NARROW = 0 / 1: never /
+            // wherever the plane divides.
+            auto sc = [&](int td, int th, int tw, double eff, int kmul) {
+                const long long t = (long long)d.n * ceil_div(p->Dr, td) * ceil_div(p->Hr, th) * ceil_div(p->Wr, tw);
+                const long long b = t * ceil_div(d.cout, 128) * kmul;
+                const double useful = (double)rows * d.n / ((double)t * td * th * tw);
+                return useful * (double)b / (double)(((b + 255) / 256) * 256) * eff;
+            };
+            double cur;
+            if (p->halo3 == 7) {
+                const int km = p->ksplit == 2 ? 2 : 1;
+                cur = p->m512_w16 == 5 ? sc(3, 8, 16, 1.1, km) : p->m512_w16 == 3 ? sc(3, 4, 32, 1.1, 1)
+                      : p->m512_w16 == 2 ? sc(4, 8, 16, 1.15, 1) : sc(4, 4, 32, 1.15, km);
+            } else if (p->halo3 == 2) {
+                cur = p->h32_w16 == 2 ? sc(3, 4, 16, 0.95, 1) : p->h32_w16 == 1 ? sc(4, 4, 16, 1.0, 1) : sc(4, 2, 32, 1.0, 1);
+            } else {
+                cur = 0.6;      // the gather kernel (halo tiles wasted > 30 % of their rows)
+            }
+            const char* nw = getenv("CTSI_CONV_K32_NARROW");
+            const bool off = nw && !strcmp(nw, "0"), force = nw && !strcmp(nw, "1");
+            struct { int td, th, tw, code; } cand[2] = {{4, 4, 24, 6}, {8, 4, 12, 7}};
+            for (auto& c : cand) {
+                if (off || p->halo3 == 6 || p->Wr % c.tw != 0 || p->Wr % 16 == 0) continue;
+                if (force || sc(c.td, c.th, c.tw, 1.07, 1) > 1.05 * cur) {
+                    p->halo3 = 7;
+                    p->BM = 384;
+                    p->BN = 128;
+                    p->h32_w16 = 0;
+                    p->m512_w16 = c.code;
+                    p->ksplit = 0;
+                    break;
+                }
+            }
+        }
         // ConvTranspose3d (3,4,4) / (1,2,2) on the k32 kernel: each parity class is a 12-tap convolution on the input grid with
         // the 3x3x3 conv's halo tile (conv3_halo_k32.hip, TR = true); CTSI_CONV_K32T=0 keeps the gather kernel (A/B timing)
         if (d.transposed && d.c2 == 0 && d.c1 % 16 == 0 && d.cout >= 64 && d.cout % 8 == 0 && p->CinW == p->Cin &&
             extent < 2.0e9) {
             // tile: useful fraction of the tile rows x fill of the 256 CUs (4 classes x n-tiles blocks per input tile) x relative
             // efficiency (384-voxel tiles 0.96)
-            struct { int td, th, tw, code; double eff; } cand[4] = {{4, 4, 32, 0, 1.0}, {4, 8, 16, 2, 1.0}, {3, 4, 32, 3, 0.96},
-                                                                    {3, 8, 16, 5, 0.96}};
+            // (4x4x24 / 8x4x12: the straddling 384-voxel tiles for 24- / 12-wide input planes, only where the plane divides)
+            struct { int td, th, tw, code; double eff; } cand[6] = {{4, 4, 32, 0, 1.0}, {4, 8, 16, 2, 1.0}, {3, 4, 32, 3, 0.96},
+                                                                    {3, 8, 16, 5, 0.96}, {4, 4, 24, 6, 0.96}, {8, 4, 12, 7, 0.96}};
             double best = -1.0, best_useful = 0.0;
             int best_code = 0;
             for (auto& c : cand) {
+                if (c.code >= 6 && (p->Wr % c.tw != 0 || p->Wr % 16 == 0 || getenv("CTSI_CONV_K32_NARROW_TD") == nullptr)) continue;
                 const long long t = (long long)d.n * ceil_div(p->Dr, c.td) * ceil_div(p->Hr, c.th) * ceil_div(p->Wr, c.tw);
                 const long long b = t * 4 * ceil_div(d.cout, 128);
                 const double useful = (double)rows * d.n / ((double)t * c.td * c.th * c.tw);
@@ -1082,7 +1124,7 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 const char* t384 = getenv("CTSI_CONV_K32_384");   // "1": a 384-voxel tile of that width (test aid)
                 if (t384 && !strcmp(t384, "1")) p->m512_w16 = (p->m512_w16 == 2 || p->m512_w16 == 5) ? 5 : 3;
                 if (t384 && !strcmp(t384, "0")) p->m512_w16 = (p->m512_w16 == 2 || p->m512_w16 == 5) ? 2 : 0;
-                p->BM = (p->m512_w16 == 3 || p->m512_w16 == 5) ? 384 : 512;
+                p->BM = (p->m512_w16 == 3 || p->m512_w16 >= 5) ? 384 : 512;
             }
         }
         // Strided Conv3d (3,4,4) / (1,2,2) / pad 1 (Downsample3D, the VAE encoder's DownsampleBlock) on the k32 kernel: the four
@@ -1092,12 +1134,13 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
         if (!d.transposed && d.kd == 3 && d.kh == 4 && d.kw == 4 && d.sh == 2 && d.sw == 2 && d.pd == 1 && d.ph == 1 && d.pw == 1 &&
             d.c2 == 0 && d.c1 % 16 == 0 && d.cout >= 64 && d.cout % 8 == 0 && p->CinW == p->Cin && d.hi % 2 == 0 && d.wi % 2 == 0 &&
             extent < 2.0e9) {
-            struct { int td, th, tw, code; double eff; } cand[4] = {{4, 4, 32, 0, 1.0}, {4, 8, 16, 2, 1.0}, {3, 4, 32, 3, 0.96},
-                                                                    {3, 8, 16, 5, 0.96}};
+            struct { int td, th, tw, code; double eff; } cand[6] = {{4, 4, 32, 0, 1.0}, {4, 8, 16, 2, 1.0}, {3, 4, 32, 3, 0.96},
+                                                                    {3, 8, 16, 5, 0.96}, {4, 4, 24, 6, 0.96}, {8, 4, 12, 7, 0.96}};
             double best = -1.0, best_useful = 0.0;
             int best_code = 0;
             long long best_blocks = 0;
             for (auto& c : cand) {
+                if (c.code >= 6 && (p->Wr % c.tw != 0 || p->Wr % 16 == 0 || getenv("CTSI_CONV_K32_NARROW_TD") == nullptr)) continue;
                 const long long t = (long long)d.n * ceil_div(p->Dr, c.td) * ceil_div(p->Hr, c.th) * ceil_div(p->Wr, c.tw);
                 const long long b = t * ceil_div(d.cout, 128);
                 const double useful = (double)rows * d.n / ((double)t * c.td * c.th * c.tw);
@@ -1134,7 +1177,7 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                     p->m512_w16 = 5;
                     p->ksplit = 2;
                 }
-                p->BM = (p->m512_w16 == 3 || p->m512_w16 == 5) ? 384 : 512;
+                p->BM = (p->m512_w16 == 3 || p->m512_w16 >= 5) ? 384 : 512;
             }
         }
         // few output channels (network heads: 128 -> 8, 128 -> 1): halo tile 4x2x16 x 16 couts, see conv3_head.hip
@@ -1149,7 +1192,11 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
     }
     p->CoutPad = ceil_div(d.cout, p->BN) * p->BN;
     p->ntiles_n = p->CoutPad / p->BN;
-    if (p->halo3 == 7 && p->m512_w16 == 5) {
+    if (p->halo3 == 7 && p->m512_w16 == 6) {
+        p->TD = 4; p->TH = 4; p->TW = 24;
+    } else if (p->halo3 == 7 && p->m512_w16 == 7) {
+        p->TD = 8; p->TH = 4; p->TW = 12;
+    } else if (p->halo3 == 7 && p->m512_w16 == 5) {
         p->TD = 3; p->TH = 8; p->TW = 16;
     } else if (p->halo3 == 7 && p->m512_w16 == 3) {
         p->TD = 3; p->TH = 4; p->TW = 32;

@@ -716,12 +716,18 @@ extern "C" double ctsi_wgrad_flops(const ctsi_wgrad_desc* d) {
     return 2.0 * (double)g.V * d->cr * d->cg * g.T;
 }
 
-extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* gt, void* workspace, float* dw,
-                          long long stride_r, long long stride_g, long long stride_t, float scale, void* stream) {
+extern "C" int ctsi_wgrad(const ctsi_wgrad_desc* d, const void* r, const void* gt, void* workspace, size_t workspace_bytes,
+                          float* dw, long long stride_r, long long stride_g, long long stride_t, float scale, void* stream) {
     WgradGeom g;
     int rc = wg_geometry(d, &g);
     if (rc != CTSI_OK) return rc;
     CTSI_CHECK_ARG(r && gt && workspace && dw, "ctsi_wgrad: null pointer");
+    {   // the kernel family (and with it the partial-sum layout) is chosen at launch from the tuning switches of the moment
+        // (CTSI_WGRAD_HALO / _S1 / _TARGET): a workspace sized under other settings must fail here, not be written past its end
+        const size_t need = ctsi_wgrad_workspace_bytes(d);
+        CTSI_CHECK_ARG(workspace_bytes >= need, "ctsi_wgrad: workspace of %zu bytes, this launch needs %zu (sized under other "
+                       "CTSI_WGRAD_* settings?)", workspace_bytes, need);
+    }
     {
         int hS = 0, hCRp = 0, hCGp = 0;
         if (wg_use_halo(d, &hS, nullptr, &hCRp, &hCGp)) {

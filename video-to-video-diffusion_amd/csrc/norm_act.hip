@@ -100,6 +100,10 @@ extern "C" int ctsi_gn_colsum(const void* x, float* colsum, int n, int c, int d,
 // partials per group, 71 us per launch when ONE block read them): slice s of a (sample, group) sums items
 // [s * per, (s + 1) * per) the same way, parks its pair in a scratch row (agent-scope stores) and takes a ticket; the block that
 // draws the last ticket adds the S pairs IN SLICE ORDER and writes the result: still no dependence on block scheduling.
+// The scratch rows and tickets are process-global and the slot rotates per call: launches that could run CONCURRENTLY on one
+// device (two streams, two host threads, two graphs replayed side by side) must not both take the split form -- the engine
+// issues everything of a device on ONE stream (Ctx), which is what makes this safe; a caller that cannot promise that sets
+// CTSI_GN_FIN_SPLIT=0.
 #define GN_FIN_ROWS 2048
 #define GN_FIN_SMAX 16
 #define GN_FIN_SLOTS 4
@@ -413,7 +417,7 @@ extern "C" int ctsi_gn_apply(const void* x, void* y, const double* sums, const f
         }
     }
     const size_t lds = (size_t)c * 3 * sizeof(float);
-    // tensors beyond the Infinity Cache (256 MB) are streamed with non-temporal accesses (CTSI_GN_NT=0 / 1 overrides)
+    // tensors well beyond the 256 MB Infinity Cache (> 512 MB: measured threshold) are streamed with non-temporal accesses (CTSI_GN_NT=0 / 1 overrides)
     static const char* nt_env = getenv("CTSI_GN_NT");
     const bool nt = nt_env ? atoi(nt_env) != 0 : (long long)n * vox * c * 2 > (512ll << 20);
     const int idx = (silu_pre ? 1 : 0) | (tbias ? 2 : 0) | (residual ? 4 : 0) | (silu_post ? 8 : 0) | (constq ? 16 : 0) | (nt ? 32 : 0);

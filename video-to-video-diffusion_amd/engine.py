@@ -346,8 +346,17 @@ class Program:
     # weight images (weight_cache False: the training program) take this path; operands it cannot express (values that are
     # not contiguous views of parameter storage) keep their generic refresh function.
     def _param_view(self, t: torch.Tensor) -> bool:
-        return (torch.is_tensor(t) and t.is_cuda and t.device == self.ctx.device and t.dtype == torch.float32
-                and t.is_contiguous() and t.numel() > 0)
+        """A contiguous fp32 view INTO THE STORAGE OF A TRACKED PARAMETER: only such an address is still the value's home
+        after the next optimizer step (a temporary -- cat, scaled copy, matmul result -- passes every other test, and its
+        freed address would be baked into the pointer table and the recorded graph)."""
+        if not (torch.is_tensor(t) and t.is_cuda and t.device == self.ctx.device and t.dtype == torch.float32
+                and t.is_contiguous() and t.numel() > 0):
+            return False
+        homes = getattr(self, "_param_storages", None)
+        if homes is None or self._param_storages_n != len(self._params):
+            homes = self._param_storages = {p.untyped_storage().data_ptr() for p in self._params if torch.is_tensor(p)}
+            self._param_storages_n = len(self._params)
+        return t.untyped_storage().data_ptr() in homes
 
     def _build_fast(self):
         import struct
@@ -390,6 +399,10 @@ class Program:
                 packs.append((lib.conv_plan_pack_weights, (plan, C.c_void_p(wt.data_ptr()), dst, sptr)))
             else:
                 slow.append(ent["fn"])
+        # refresh functions registered outside the two tables (an attention block's folded matrix, the packs of an overlapped
+        # depth-sharded conv) have no fast form: they run as they are, and keep the step out of the recorded graph
+        known = {id(ent["fn"]) for ent in self._f32_meta} | {id(ent["fn"]) for ent in self._pack_meta}
+        slow.extend(fn for fn in self.pack_fns if id(fn) not in known and fn not in slow)
         seg_bytes = b"".join(struct.pack("<QQqfi", s_, d_, n_, sc, 0) for (s_, d_, n_, sc) in segs)
         pieces = [(i, q) for i, (_, _, n_, _) in enumerate(segs) for q in range((n_ + 4095) // 4096)]
         pc_bytes = b"".join(struct.pack("<ii", i, q) for (i, q) in pieces)
@@ -412,13 +425,17 @@ class Program:
                 # every launch of the list has constant arguments: record it once, replay it as ONE hipGraph afterwards
                 # (240 launches for the training program: ~1 ms of ctypes calls otherwise)
                 self.lib.graph_begin_capture(self.ctx.sptr)
+                ok = False
                 try:
                     self.lib.copy_scale_multi(_ptr(f["segs"]), _ptr(f["pieces"]), f["npieces"], self.ctx.sptr)
                     for fn, args in f["packs"]:
                         fn(*args)
+                    ok = True
                 finally:
                     g = C.c_void_p()
                     self.lib.graph_end_capture(self.ctx.sptr, C.byref(g))
+                    if not ok and g:          # a launch failed under capture: the partial graph must not be replayed
+                        self.lib.graph_destroy(g)
                 f["graph"] = g
             if f.get("graph") is not None:
                 self.lib.graph_launch(f["graph"], self.ctx.sptr)

@@ -310,16 +310,19 @@ class DDIMSampler:
     @torch.no_grad()
     def sample_with_stitching(self, v_thick_full, vae, num_inference_steps=20, patch_size=(8, 192, 192),
                               target_patch_size=(48, 192, 192), stride=(4, 96, 96), device='cuda', eta=0.0,
-                              progress=True, window_batch=8, dp_group=None):
+                              progress=True, window_batch=None, dp_group=None):
         """`dp_group` (additive kwarg, default None = every window on this process, as in the reference): a
         torch.distributed process group (or True for the default group) over which the windows are split; every rank
         of the group must make the call with the SAME volume.
         `window_batch` (additive kwarg): windows are independent, so for the deterministic sampler (eta == 0) up to
         that many are encoded / sampled / decoded as one batch -- a single 192x192 patch leaves most of an MI355X
-        idle (its coarsest level has 28 conv tiles for 256 CUs).  The initial noise of every window is still drawn
+        idle (its coarsest level has 28 conv tiles for 256 CUs).  None / 0 (default): as many as the device memory holds
+        (all 25 windows of a 512 x 512 volume on a 288 GB part); 1: one by one, like the reference.  The initial noise of every window is still drawn
         with its own `torch.randn` call in window order, exactly as the reference's one-by-one loop draws it."""
         batched = None
-        if float(eta) == 0.0 and window_batch > 1:
+        if window_batch is None:
+            window_batch = 0          # 0 = as many windows per batch as the device memory holds (see _stitched)
+        if float(eta) == 0.0 and window_batch != 1:
             batched = lambda shp, cond, z_init: self.sample(shp, cond, num_inference_steps, device, eta=0.0,
                                                             progress=False, z_init=z_init)
         return _stitched(self, v_thick_full, vae, patch_size, target_patch_size, stride, device, progress,
@@ -401,7 +404,18 @@ def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride,
     it = None
     if progress and tqdm is not None:
         it = tqdm(desc="Patch-based inference", total=len(mine))
-    group = max(1, int(window_batch)) if batched_fn is not None else 1
+    group = 1
+    if batched_fn is not None:
+        group = int(window_batch)
+        if group <= 0:
+            # every window the device memory holds at once: the VAE decoder is the largest program, ~2.4 KB of activations per
+            # output voxel (30 GB for a 48 x 512 x 512 volume); 60 % of the free memory, the rest stays with the caller
+            try:
+                free = torch.cuda.mem_get_info(ctx.device)[0]
+            except Exception:
+                free = 64 << 30
+            per_window = 2500.0 * b * td * th * tw
+            group = max(1, min(len(mine), int(0.6 * free / per_window)))
     ngroups = max(1, -(-len(mine) // group))            # balanced groups: 25 windows, window_batch 8 -> 7 + 6 + 6 + 6
     bounds = [round(i * len(mine) / ngroups) for i in range(ngroups + 1)]
     for gi in range(ngroups):

@@ -271,7 +271,7 @@ class UNetTrainProgram(Program):
             rp, gp2, dwp = r_act.ip, g_act.ip, C.c_void_p(gw.data_ptr() + 4 * off)
 
             def run_w(desc=desc, rp=rp, gp2=gp2, dwp=dwp, sr=sr, sg=sg):
-                lib.wgrad(C.byref(desc), rp, gp2, prog._ws_ptr("wgrad"), dwp, sr, sg, 1, 1.0, sptr)
+                lib.wgrad(C.byref(desc), rp, gp2, prog._ws_ptr("wgrad"), prog._ws["wgrad"].numel(), dwp, sr, sg, 1, 1.0, sptr)
 
             self._emit(run_w, name + ".wgrad", fl, "conv_wgrad")
         # data

@@ -209,8 +209,8 @@ def test_conv3_halo_k32_narrow_plane_tiles(G, monkeypatch, name, c1, c2, cout, d
                                                 ("down", 128, 128, (1, 8, 16, 48)), ("down", 64, 192, (2, 16, 8, 24))],
                          ids=["convT_in24", "convT_in12_batch2", "down_out24", "down_out12_batch2"])
 def test_narrow_plane_tiles_transposed_and_strided_forms(G, monkeypatch, kind, cin, cout, dims):
-    """ConvTranspose3d / strided Conv3d (3,4,4)/(1,2,2) on the 4x4x24 / 8x4x12 tiles of the k32 kernel (opt-in:
-    CTSI_CONV_K32_NARROW_TD), against fp32 torch and against the 16-wide tiles."""
+    """ConvTranspose3d / strided Conv3d (3,4,4)/(1,2,2) on the 4x4x24 / 8x4x12 tiles of the k32 kernel, against fp32 torch and
+    against the 16-wide tiles (CTSI_CONV_K32_NARROW=0)."""
     n, d, h, w = dims
     x = bf16_round(formula_input((n, cin, d, h, w), 1))
     b = formula_input((cout,), 4) * 0.1
@@ -222,11 +222,10 @@ def test_narrow_plane_tiles_transposed_and_strided_forms(G, monkeypatch, kind, c
         wt = bf16_round(_w((cout, cin, 3, 4, 4), 5))
         ref = F.conv3d(x, wt, b, stride=(1, 2, 2), padding=(1, 1, 1))
         kw = dict(k=(3, 4, 4), s=(2, 2))
-    monkeypatch.setenv("CTSI_CONV_K32_NARROW_TD", "1")
     monkeypatch.setenv("CTSI_CONV_FORCE_HALO3", "1")
     y, _ = G.run_conv(x, None, wt, b, **kw)
     assert rel_l2(y, ref) < CONV_TOL
-    monkeypatch.delenv("CTSI_CONV_K32_NARROW_TD")
+    monkeypatch.setenv("CTSI_CONV_K32_NARROW", "0")
     y2, _ = G.run_conv(x, None, wt, b, **kw)
     assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
 

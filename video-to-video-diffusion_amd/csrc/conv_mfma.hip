@@ -1095,13 +1095,15 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             extent < 2.0e9) {
             // tile: useful fraction of the tile rows x fill of the 256 CUs (4 classes x n-tiles blocks per input tile) x relative
             // efficiency (384-voxel tiles 0.96)
-            // (4x4x24 / 8x4x12: the straddling 384-voxel tiles for 24- / 12-wide input planes, only where the plane divides)
+            // (4x4x24 / 8x4x12: the straddling 384-voxel tiles for 24- / 12-wide input planes, only where the plane divides:
+            //  25 stitching windows at once, Upsample + Downsample layers 12.4 -> 11.1 ms; CTSI_CONV_K32_NARROW=0: never)
+            const bool narrow_off = getenv("CTSI_CONV_K32_NARROW") && !strcmp(getenv("CTSI_CONV_K32_NARROW"), "0");
             struct { int td, th, tw, code; double eff; } cand[6] = {{4, 4, 32, 0, 1.0}, {4, 8, 16, 2, 1.0}, {3, 4, 32, 3, 0.96},
                                                                     {3, 8, 16, 5, 0.96}, {4, 4, 24, 6, 0.96}, {8, 4, 12, 7, 0.96}};
             double best = -1.0, best_useful = 0.0;
             int best_code = 0;
             for (auto& c : cand) {
-                if (c.code >= 6 && (p->Wr % c.tw != 0 || p->Wr % 16 == 0 || getenv("CTSI_CONV_K32_NARROW_TD") == nullptr)) continue;
+                if (c.code >= 6 && (p->Wr % c.tw != 0 || p->Wr % 16 == 0 || narrow_off)) continue;
                 const long long t = (long long)d.n * ceil_div(p->Dr, c.td) * ceil_div(p->Hr, c.th) * ceil_div(p->Wr, c.tw);
                 const long long b = t * 4 * ceil_div(d.cout, 128);
                 const double useful = (double)rows * d.n / ((double)t * c.td * c.th * c.tw);
@@ -1136,11 +1138,12 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             extent < 2.0e9) {
             struct { int td, th, tw, code; double eff; } cand[6] = {{4, 4, 32, 0, 1.0}, {4, 8, 16, 2, 1.0}, {3, 4, 32, 3, 0.96},
                                                                     {3, 8, 16, 5, 0.96}, {4, 4, 24, 6, 0.96}, {8, 4, 12, 7, 0.96}};
+            const bool narrow_off = getenv("CTSI_CONV_K32_NARROW") && !strcmp(getenv("CTSI_CONV_K32_NARROW"), "0");
             double best = -1.0, best_useful = 0.0;
             int best_code = 0;
             long long best_blocks = 0;
             for (auto& c : cand) {
-                if (c.code >= 6 && (p->Wr % c.tw != 0 || p->Wr % 16 == 0 || getenv("CTSI_CONV_K32_NARROW_TD") == nullptr)) continue;
+                if (c.code >= 6 && (p->Wr % c.tw != 0 || p->Wr % 16 == 0 || narrow_off)) continue;
                 const long long t = (long long)d.n * ceil_div(p->Dr, c.td) * ceil_div(p->Hr, c.th) * ceil_div(p->Wr, c.tw);
                 const long long b = t * ceil_div(d.cout, 128);
                 const double useful = (double)rows * d.n / ((double)t * c.td * c.th * c.tw);

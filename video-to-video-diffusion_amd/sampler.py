@@ -316,8 +316,8 @@ class DDIMSampler:
         of the group must make the call with the SAME volume.
         `window_batch` (additive kwarg): windows are independent, so for the deterministic sampler (eta == 0) up to
         that many are encoded / sampled / decoded as one batch -- a single 192x192 patch leaves most of an MI355X
-        idle (its coarsest level has 28 conv tiles for 256 CUs).  None / 0 (default): as many as the device memory holds
-        (all 25 windows of a 512 x 512 volume on a 288 GB part); 1: one by one, like the reference.  The initial noise of every window is still drawn
+        idle (its coarsest level has 28 conv tiles for 256 CUs).  None / 0 (default): as many as a fifth of the device
+        memory holds (13 windows of 48 x 192 x 192 on a 288 GB part); 1: one by one, like the reference.  The initial noise of every window is still drawn
         with its own `torch.randn` call in window order, exactly as the reference's one-by-one loop draws it."""
         batched = None
         if window_batch is None:
@@ -408,14 +408,17 @@ def _stitched(sampler, v_thick_full, vae, patch_size, target_patch_size, stride,
     if batched_fn is not None:
         group = int(window_batch)
         if group <= 0:
-            # every window the device memory holds at once: the VAE decoder is the largest program, ~2.4 KB of activations per
-            # output voxel (30 GB for a 48 x 512 x 512 volume); 60 % of the free memory, the rest stays with the caller
+            # as many windows per batch as a fifth of the DEVICE memory holds: the VAE decoder is the largest program, ~2.5 KB of
+            # activations per output voxel (30 GB for a 48 x 512 x 512 volume, 4.4 GB per 48 x 192 x 192 window: 13 windows on a
+            # 288 GB part).  Measured on 25 windows: 13 per batch 1.69 s, all 25 at once 1.72 s, 5 per batch 1.98 s -- past a dozen
+            # windows the levels are full and more only costs memory.  The TOTAL memory (not the free memory of the moment) keeps
+            # the batch shape, and with it the cached programs, the same from call to call.
             try:
-                free = torch.cuda.mem_get_info(ctx.device)[0]
+                total = torch.cuda.get_device_properties(ctx.device).total_memory
             except Exception:
-                free = 64 << 30
+                total = 64 << 30
             per_window = 2500.0 * b * td * th * tw
-            group = max(1, min(len(mine), int(0.6 * free / per_window)))
+            group = max(1, min(len(mine), int(0.2 * total / per_window)))
     ngroups = max(1, -(-len(mine) // group))            # balanced groups: 25 windows, window_batch 8 -> 7 + 6 + 6 + 6
     bounds = [round(i * len(mine) / ngroups) for i in range(ngroups + 1)]
     for gi in range(ngroups):

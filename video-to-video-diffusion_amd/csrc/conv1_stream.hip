@@ -30,8 +30,11 @@ conv1_stream_kernel(const Conv1StreamParams p) {
     constexpr int KS = NCH * 4, BN = NT * 16, W_BYTES = KS * NT * 1024;
     static_assert(NT % 2 == 0, "a lane stores its couts in 16-byte pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // scale / shift table: row g (the 4 NT couts of lane group g) padded by 8 floats -- with 256-cout n-tiles the four groups'
+    // 16-byte reads were exactly 256 B apart, i.e. on the same banks (16-24 % LDS bank conflicts in the first PMC pass)
+    constexpr int GS = 4 * NT + 8;
     float* s_sc = reinterpret_cast<float*>(smem + W_BYTES);
-    float* s_sh = s_sc + BN;
+    float* s_sh = s_sc + 4 * GS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -60,8 +63,8 @@ conv1_stream_kernel(const Conv1StreamParams p) {
             sc = p.gn_gamma[co] * rstd;
             sh += p.gn_beta[co] - (float)mean * sc;
         }
-        s_sc[tid] = sc;
-        s_sh[tid] = sh;
+        s_sc[(tid / (4 * NT)) * GS + tid % (4 * NT)] = sc;
+        s_sh[(tid / (4 * NT)) * GS + tid % (4 * NT)] = sh;
     }
 
     const long long vb = (long long)nb * p.V;
@@ -144,10 +147,10 @@ conv1_stream_kernel(const Conv1StreamParams p) {
 #pragma unroll
             for (int q = 0; q < NT / 2; ++q) {
                 float sc[8], sh[8];
-                *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(s_sc + g * (4 * NT) + q * 8);
-                *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(s_sc + g * (4 * NT) + q * 8 + 4);
-                *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(s_sh + g * (4 * NT) + q * 8);
-                *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(s_sh + g * (4 * NT) + q * 8 + 4);
+                *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(s_sc + g * GS + q * 8);
+                *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(s_sc + g * GS + q * 8 + 4);
+                *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(s_sh + g * GS + q * 8);
+                *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(s_sh + g * GS + q * 8 + 4);
                 const uint4 hv = has_h ? hr[q] : make_uint4(0, 0, 0, 0);
                 const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
                 const float cv[8] = {acc[2 * q][0], acc[2 * q][1], acc[2 * q][2], acc[2 * q][3],
@@ -224,7 +227,7 @@ extern "C" int ctsi_conv1_stream_pack(const float* w, void* packed, int cout, in
 
 template <int NCH, int NT, int NW>
 static int c1s_launch(const Conv1StreamParams& q, int n, hipStream_t stream) {
-    constexpr int LDS = NCH * 4 * NT * 1024 + 2 * NT * 16 * 4;
+    constexpr int LDS = NCH * 4 * NT * 1024 + 2 * 4 * (4 * NT + 8) * 4;
     static_assert(LDS <= 160 * 1024, "weight image does not fit");
     auto k = conv1_stream_kernel<NCH, NT, NW>;
     static CtsiPerDeviceOnce attr_once;

@@ -416,6 +416,10 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         HK_LOAD_A(fa0, 2, aaddr);
         HK_LOAD_B(fbl, 0, b_lane, 0);
     }
+    if (CTSI_DBG(p.dbg, 128)) {      // timing-only (ablation builds): the second B half is never loaded -- 0.25 LDS reads per MFMA
+#pragma unroll
+        for (int j = 0; j < NJH; ++j) fbh[j] = fbl[j];
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- main loop ------------------------------------------------------------------------------------------------------------
@@ -460,7 +464,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     // one unit: FAc = this unit's A fragments (fbl holds its first B half), FAn receives the next unit's
 #define HK_UNIT(FAc, FAn, BADDR, UU, BADDR_N, UU_N, AADDR_N, MID)                                              \
     {                                                                                                          \
-        HK_LOAD_B(fbh, NJH, BADDR, UU);                                                                        \
+        if (!(CTSI_DBG(p.dbg, 128))) HK_LOAD_B(fbh, NJH, BADDR, UU);   /* (128, ablation builds: 8 instead of 12 reads per unit) */ \
         HK_LOAD_A(FAn, 0, AADDR_N);                                                                            \
         HK_MFMA(FAc, fbl, 0);                                                                                  \
         HK_SCHED();                                                                                            \

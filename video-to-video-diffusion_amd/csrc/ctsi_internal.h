@@ -132,7 +132,7 @@ struct Conv3HaloParams {
     int Cout, CoutPad;
     int cout_stride, c_off;
     int n_major;          // block order inside an XCD: 1 = all m-tiles of one n-tile first (see h3_decode_tile)
-    int dbg;              // ablation bits (0 in production): 1 no halo DMA after chunk 0, 2 no weight DMA after step 1, 4 no
+    int dbg;              // ablation bits (compiled out of libctsi.so, see CTSI_DBG): 128 (k32) no loads of a unit's second B half; 1 no halo DMA after chunk 0, 2 no weight DMA after step 1, 4 no
                           // global stores, 8 no epilogue (1-8: wrong results, timing only); 16 / 32: DMA pieces issued right behind
                           // the step's barrier / at the end of the step instead of behind the first MFMA phase (correct results)
     // normalise-on-load (experiments/conv3_halo_m512.hip only; no kernel of libctsi.so reads these): the input is the RAW output of the previous conv; the kernel

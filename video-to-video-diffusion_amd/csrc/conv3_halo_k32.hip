@@ -33,6 +33,17 @@
 //     1.5-3 % SLOWER there than conv3_halo32_kernel's 768 blocks of 256 x 128 (1126-1159 vs 1148-1176 TFLOP/s; 0.5 LDS reads per
 //     MFMA instead of 0.375 and twice the halo DMA per FLOP eat the MFMA-shape gain): NOT instantiated or dispatched
 //     (profiles/r02_notes.md).
+// Epilogue form (round 4), template parameter DIRECT.  DIRECT: packed row 16 j + r of an n-tile holds cout NJ r + j, so that lane
+// r16 ends up with the NJ = 8 CONSECUTIVE couts NJ r16 .. NJ r16 + 7 of each of its 16 voxel rows and stores them as 16-byte pieces
+// straight from the accumulators (a store instruction of a wave = 4 voxel rows x 256 contiguous bytes): no 128 KB tile through
+// LDS, no 2-byte LDS writes, no row re-reads.  Staged (round 2): the bf16 tile goes through LDS, packed row = cout.  The two forms
+// use different packed weight images (ctsi_conv3_halo_k32_pack's `direct`).  Same-box alternation of whole bench runs
+// (profiles/r04_epilogue_ab.log): 512-voxel tiles -1.8 % (plain), -2.1 % (ConvTranspose), -0.7 % (split-K), the 384-voxel split-K
+// form -4.3 %; the PLAIN 384-voxel tiles +3 % (slower) and their Downsample forms +-0: ctsi_conv3_halo_k32_direct() picks per form.
+// cout (within the block's n-tile) of accumulator column r16 of cout tile j
+template <int NJ, bool DIRECT>
+__device__ __forceinline__ int hk_col(int j, int r16) { return DIRECT ? r16 * NJ + j : j * 16 + r16; }
+
 template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2>
 struct HkCfg {
     static constexpr int TD = TD_, TH = TH_, TW = TW_, UPS = UPS_;
@@ -118,7 +129,7 @@ __device__ unsigned long long g_hk_stamps[HK_NSTAMP][8];
 #define HK_STAMP(K)                                                                                              \
     if ((CTSI_DBG(p.dbg, 4096)) && tid == 0 && blockIdx.x < HK_NSTAMP) g_hk_stamps[blockIdx.x][K] = __builtin_amdgcn_s_memtime();
 
-template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false, bool SK = false, bool DS = false>
+template <int TD_, int TH_, int TW_ = 32, int BN_ = 128, int UPS_ = 2, bool TR = false, bool SK = false, bool DS = false, bool DIRECT = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, 512)))
 conv3_halo_k32_kernel(const Conv3HaloParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -403,7 +414,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     // the accumulators start at the bias of their cout (split-K: in the first half only): no bias pass in the epilogue
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const float bv = has_bias ? s_cs[j * 16 + r16] : 0.0f;
+        const float bv = has_bias ? s_cs[hk_col<NJ, DIRECT>(j, r16)] : 0.0f;
 #pragma unroll
         for (int i = 0; i < MA; ++i)
 #pragma unroll
@@ -592,7 +603,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         constexpr bool MASKED = decltype(masked_tag)::value, SUMS = decltype(sums_tag)::value;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int col = j * 16 + r16;
+            const int col = hk_col<NJ, DIRECT>(j, r16);
             float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
             for (int i = 0; i < MA; ++i) {
@@ -625,7 +636,69 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             }
         }
     };
-    {
+    bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+    if constexpr (DIRECT) {
+        // direct form: lane (kg, r16) owns couts NJ r16 .. NJ r16 + NJ - 1 of voxel rows 16 i + 4 kg + q: one 16-byte store per
+        // (i, q) straight from the accumulators; the column sums of the lane's NJ couts are taken in the same sweep (the
+        // accumulators of a row die with its store: a separate sums pass keeps all 128 alive next to the store addresses and
+        // made hipcc spill)
+        static_assert(NJ == 8, "a lane's couts of one voxel are one 16-byte piece");
+        const int co = n0 + r16 * NJ;
+        const bool co_ok = co < p.Cout;
+        auto direct_out = [&](auto masked_tag, auto sums_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value, SUMS = decltype(sums_tag)::value;
+            float s1[NJ], s2[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MA; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long long off = s_rowoff[wave * 16 * MA + 16 * i + 4 * kg + q];
+                    if (SUMS) {
+                        const bool live = !MASKED || ((vbits >> (4 * i + q)) & 1u);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const float m = live ? acc[i][j][q] : 0.0f;
+                            s1[j] += m;
+                            s2[j] = __builtin_fmaf(m, m, s2[j]);
+                        }
+                    }
+                    if (off >= 0 && co_ok && !(CTSI_DBG(p.dbg, 4))) {
+                        typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+                        u4_t w4;
+                        w4.x = pack_bf16x2_v(f32x2_t{acc[i][0][q], acc[i][1][q]});
+                        w4.y = pack_bf16x2_v(f32x2_t{acc[i][2][q], acc[i][3][q]});
+                        w4.z = pack_bf16x2_v(f32x2_t{acc[i][4][q], acc[i][5][q]});
+                        w4.w = pack_bf16x2_v(f32x2_t{acc[i][6][q], acc[i][7][q]});
+                        if (p.nt_store)       // streaming (non-temporal) stores: see ctsi_conv_fwd
+                            __builtin_nontemporal_store(w4, reinterpret_cast<u4_t*>(y + off + co));
+                        else
+                            *reinterpret_cast<u4_t*>(y + off + co) = w4;
+                    }
+                }
+            if (SUMS) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    float a1 = s1[j], a2 = s2[j];
+                    a1 += __shfl_xor(a1, 16);
+                    a2 += __shfl_xor(a2, 16);
+                    a1 += __shfl_xor(a1, 32);
+                    a2 += __shfl_xor(a2, 32);
+                    if (kg == 0) {
+                        s_cs[(wave * BN + r16 * NJ + j) * 2 + 0] = a1;
+                        s_cs[(wave * BN + r16 * NJ + j) * 2 + 1] = a2;
+                    }
+                }
+            }
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        const bool ragged = __builtin_amdgcn_ballot_w64(vbits != (1u << (4 * MA)) - 1u) != 0ull;   // wave-uniform
+        if (!want_sums) direct_out(F{}, F{});
+        else if (ragged) direct_out(T{}, T{});
+        else direct_out(F{}, T{});
+    } else {
         using T = std::true_type;
         using F = std::false_type;
         const bool ragged = __builtin_amdgcn_ballot_w64(vbits != (1u << (4 * MA)) - 1u) != 0ull;   // wave-uniform
@@ -638,8 +711,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     // cross-wave column sums while the stores drain.  (The other order -- barrier and sums first, nothing behind the last store --
     // measured 1.8 k cycles per tile slower: the store drain then sits in the hand-over to the next block.)
     constexpr int CPR = BN / 8;
-    bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
-    {
+    if constexpr (!DIRECT) {
         constexpr int RPW = 16 * MA;
 #pragma unroll 4
         for (int k = 0; k < RPW * CPR / 64; ++k) {
@@ -684,7 +756,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
 //      ConvTranspose3d (cin, cout, 3,4,4) -> [class][entry q = chunk16 * 12 + t][cout_pad][16], t = (a * 2 + b) * 2 + c with
 //      kernel taps k_d = 2 - a (halo slices ascending), k_h = (py ? {2, 0} : {1, 3})[b], k_w likewise (the tap order conv3_halo_k32_kernel<TR> walks)
 __global__ void conv3_halo_k32_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int CoutPad,
-                                           int CinW, int nchunks, long long per_class, int form) {
+                                           int CinW, int nchunks, long long per_class, int form, int bn, int direct) {
     // form 0: 3x3x3; 1: ConvTranspose3d (3,4,4)/(1,2,2) (4 class images); 2: Conv3d (3,4,4)/(1,2,2) (nchunks = 4 virtual chunks
     // per 16 input channels: vc = 4 * chunk + class, entry t = (a * 2 + b) * 2 + c <-> k_d = a, k_h = 2 b + 1 - py, k_w = 2 c + 1 - px)
     const bool transposed = form == 1;
@@ -697,7 +769,9 @@ __global__ void conv3_halo_k32_pack_kernel(const float* __restrict__ w, bf16_t* 
         const long long in_class = idx - cls * per_class;
         const int e = (int)(in_class & 15);
         const long long row = in_class >> 4;           // q * CoutPad + cout
-        const int co = (int)(row % CoutPad);
+        const int co_p = (int)(row % CoutPad);           // packed row
+        // direct epilogue form: packed row 16 j + r of a bn-cout n-tile holds cout (bn / 16) r + j (see hk_col)
+        const int co = direct ? (co_p / bn) * bn + (co_p % 16) * (bn / 16) + (co_p % bn) / 16 : co_p;
         const long long q = row / CoutPad;
         float v = 0.0f;
         if (q < Q) {
@@ -729,7 +803,7 @@ extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad, int bn
 }
 
 extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w, int bn,
-                                        int form, void* stream) {
+                                        int form, int direct, void* stream) {
     CTSI_CHECK_ARG(w && packed && cin % 16 == 0 && (bn == 64 || bn == 128) && cout_pad % bn == 0 && (form != 1 || cin_w == cin) &&
                        form >= 0 && form <= 2,
                    "ctsi_conv3_halo_k32_pack: bad arguments");
@@ -739,15 +813,32 @@ extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, 
     const long long per_class = form == 1 ? total / 4 : total;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(conv3_halo_k32_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)packed,
-                       cout, cout_pad, cin_w, nchunks, per_class, transposed);
+                       cout, cout_pad, cin_w, nchunks, per_class, transposed, bn, direct);
     CTSI_LAUNCH_CHECK();
     return CTSI_OK;
+}
+
+// Which forms store straight from the accumulators (measured per form, see hk_col): the 512-voxel tiles in every form and the
+// 384-voxel split-K form of the plain conv; the other 384-voxel forms keep the staged epilogue.
+// (-DHK_STAGED_EPILOGUE, `make staged`: the staged epilogue everywhere, for A/B timing through CTSI_LIB.)
+extern "C" int ctsi_conv3_halo_k32_direct(int tile, int ksplit, int ds) {
+#ifdef HK_STAGED_EPILOGUE
+    return 0;
+#else
+    const bool t512 = tile == 0 || tile == 2;
+    return (t512 || (tile == 5 && ksplit == 2 && !ds)) ? 1 : 0;
+#endif
 }
 
 template <int TD, int TH, int TW, int BN, int UPS, bool TR, bool SK = false, bool DS = false>
 static void hk_launch(const Conv3HaloParams* hp, hipStream_t stream) {
     using Cfg = HkCfg<TD, TH, TW, BN, UPS>;
-    auto k = conv3_halo_k32_kernel<TD, TH, TW, BN, UPS, TR, SK, DS>;
+#ifdef HK_STAGED_EPILOGUE
+    constexpr bool DIRECT = false;
+#else
+    constexpr bool DIRECT = TD * TH * TW == 512 || (SK && !DS);
+#endif
+    auto k = conv3_halo_k32_kernel<TD, TH, TW, BN, UPS, TR, SK, DS, DIRECT>;
     static CtsiPerDeviceOnce attr_once;
     if (attr_once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(k, dim3((TR ? 4 : 1) * (SK ? 2 : 1) * hp->mtiles * hp->ntiles_n), dim3(Cfg::NTH), Cfg::LDS_BYTES, stream,

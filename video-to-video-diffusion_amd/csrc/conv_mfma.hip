@@ -1342,7 +1342,8 @@ extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float*
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
     if (p->stream1) return ctsi_conv1_stream_pack(w, packed, p->d.cout, p->Cin, p->CinW, p->stream1, stream);
     if (p->halo3 == 7)
-        return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, p->BN, p->ds ? 2 : p->d.transposed, stream);
+        return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, p->BN, p->ds ? 2 : p->d.transposed,
+                                        ctsi_conv3_halo_k32_direct(p->m512_w16, p->ksplit, p->ds), stream);
     if (p->halo3 == 6) {
         hipMemsetAsync((char*)packed + head1_bytes(p) - 1280, 0, 1280, (hipStream_t)stream);
         if (ctsi_conv3_head2_supported(p->Cin, p->d.cout)) {

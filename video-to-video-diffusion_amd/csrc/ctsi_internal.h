@@ -190,7 +190,8 @@ extern "C" int ctsi_conv1_stream_pack(const float* w, void* packed, int cout, in
 extern "C" int ctsi_conv1_stream_launch(Conv1StreamParams* q, int n, int nt, void* stream);
 extern "C" size_t ctsi_conv3_halo_k32_weight_bytes(int cin, int cout_pad, int bn, int transposed);
 extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w, int bn,
-                                        int transposed, void* stream);
+                                        int transposed, int direct, void* stream);
+extern "C" int ctsi_conv3_halo_k32_direct(int tile, int ksplit, int ds);   // 1: the form stores straight from the accumulators (cout-permuted image)
 extern "C" size_t ctsi_conv3_halo_k32_splitk_bytes(int tiles);
 extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile, int bn, void* stream);
 

@@ -551,7 +551,8 @@ class Program:
         lib.conv_plan_config(plan, C.byref(bm), C.byref(bn), C.byref(mode))
         layout = "gather" if mode.value in (0, 2) else mode.value      # the packed image depends on the kernel family,
         sig = (layout, int(transposed), tuple(k), tuple(s), x1.c, 0 if x2 is None else x2.c, cout, cin_w,   # not the shape
-               lib.conv_plan_cout_pad(plan), wbytes, bn.value)
+               lib.conv_plan_cout_pad(plan), wbytes, bn.value, bm.value, bool(lib.conv_plan_workspace_bytes(plan)))   # (k32: the
+                                                                                   # epilogue form, hence the cout order, goes by tile / split-K)
         holder: List[Optional[torch.Tensor]] = [None]
         prog = self
 
@@ -699,7 +700,7 @@ class Program:
             lib.conv_plan_config(plan, C.byref(bm), C.byref(bn), C.byref(mode))
             layout = "gather" if mode.value in (0, 2) else mode.value
             sig = (layout, 0, tuple(k), (1, 1), x1.c, 0 if x2 is None else x2.c, cout, cin_w, lib.conv_plan_cout_pad(plan),
-                   wbytes)
+                   wbytes, bn.value, bm.value, bool(lib.conv_plan_workspace_bytes(plan)))
             holder: List[Optional[torch.Tensor]] = [None]
 
             def pack(plan=plan, sig=sig, wbytes=wbytes, holder=holder):

@@ -517,7 +517,10 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
 #undef HK_SCHED
     HK_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
+    // staged / split-K forms overwrite or hand over what other waves may still be reading; the direct form touches only its own
+    // accumulators, the read-only row offsets and its own slots of the column-sum scratch until the barrier before the cross-wave
+    // sums, so its waves run into the epilogue as they finish (waves 0-3 leave the last step ~900 cycles before their partners)
+    if (!(DIRECT && !SK) || (p.dbg_epi_barrier != 0)) __syncthreads();
     HK_STAMP(3);
 
     // ---- epilogue: bias, GroupNorm column sums, the 512 x 128 bf16 tile through LDS (128 KB), 16-byte row stores -----

@@ -1506,6 +1506,8 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
             // plain order on the U-Net's 128-wide level (4 tiles per row).  CTSI_CONV_TILE_ORDER = 0 / 1 / 2 overrides (A/B timing)
             const char* to = getenv("CTSI_CONV_TILE_ORDER");
             h.tile_order = to ? atoi(to) : 2;
+            const char* eb = getenv("CTSI_CONV_EPI_BARRIER");   // "1": A/B timing of the barrier the direct epilogue drops (read per launch)
+            h.dbg_epi_barrier = eb ? atoi(eb) : 0;
         }
         if (p->halo3 == 6) {
             // second form (taps as the GEMM's N dimension, input read once straight into the MFMA layout: conv3_head2.hip) for the

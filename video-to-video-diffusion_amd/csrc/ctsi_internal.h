@@ -154,6 +154,7 @@ struct Conv3HaloParams {
     int ds;               // conv3_halo_k32_kernel: strided Conv3d (3,4,4) / (1,2,2): tiles walk the OUTPUT grid, nchunks = 4 * Cin / 16
     int tile_order;       // conv3_halo_k32_kernel: 0 = (tD, tH, tW); 1 = (tH, tD, tW); 2 = 8 x 4 super-tiles inside a depth band (see its tile decode)
     int nt_store;         // conv3_halo_k32_kernel: non-temporal output stores (large outputs: keep the L2 for halos and weights)
+    int dbg_epi_barrier;  // conv3_halo_k32_kernel, direct epilogue: keep the workgroup barrier between loop and epilogue (CTSI_CONV_EPI_BARRIER=1: A/B timing)
 };
 
 extern "C" int ctsi_conv3_halo_pack(const float* w, void* packed, int cout, int cout_pad, int cin, int cin_w,

@@ -55,9 +55,13 @@ def test_conv_plan_geometry_and_flops(lib):
     lib.conv_plan_config(p, C.byref(bm), C.byref(bn), C.byref(mode))
     assert (bm.value, bn.value, mode.value) == (512, 128, 9)     # 3x3x3, W >= 32, 1536 blocks: LDS halo-tile kernel, 4x4x32 tile,
                                                                  # tap pairs on 16x16x32 MFMAs (conv3_halo_k32.hip)
-    p2 = _plan(lib, c1=512, cout=512, hi=32, wi=32)              # 384 blocks of 512 voxels = 1.5 rounds of the CUs: the
+    p2 = _plan(lib, c1=256, cout=512, hi=32, wi=32)              # 384 blocks of 512 voxels = 1.5 rounds of the CUs: the
     lib.conv_plan_config(p2, C.byref(bm), C.byref(bn), C.byref(mode))   # 3x4x32 = 384-voxel tile gives 512 blocks = 2 rounds
-    assert (bm.value, bn.value, mode.value) == (384, 128, 9)
+    assert (bm.value, bn.value, mode.value) == (384, 128, 9) and lib.conv_plan_workspace_bytes(p2) == 0
+    lib.conv_plan_destroy(p2)
+    p2 = _plan(lib, c1=512, cout=512, hi=32, wi=32)              # from 512 input channels on: the 512-voxel tile with 2-way
+    lib.conv_plan_config(p2, C.byref(bm), C.byref(bn), C.byref(mode))   # split-K (768 half-K blocks = 3 rounds; direct-store epilogue)
+    assert (bm.value, bn.value, mode.value) == (512, 128, 9) and lib.conv_plan_workspace_bytes(p2) > 0
     lib.conv_plan_destroy(p2)
     lib.conv_plan_config(p, C.byref(bm), C.byref(bn), C.byref(mode))
     assert lib.conv_plan_tiles(p) == 48 * 128 * 128 // bm.value and lib.conv_plan_cout_pad(p) == 128

@@ -1028,10 +1028,13 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                 if (sk && !strcmp(sk, "1") && sk_ok) use_sk = true;
                 // 2-way split-K on the 4x4x32 tile: pays where the 512-voxel grid fills the CUs badly AND K is deep enough to
                 // amortise the parked accumulators (256 KB per tile): 1024 -> 512 @48x32x32 1325 -> 1400 TFLOP/s against the
-                // 384-voxel tile, 512 -> 512 +0.5 %, 256 -> 512 -7 % (profiles/r02_notes.md)
+                // 384-voxel tile, 512 -> 512 +0.5 %, 256 -> 512 -7 % (profiles/r02_notes.md).  Round 4: with the direct-store
+                // epilogue (which the split-K form takes and the plain 384-voxel tile does not) 512 -> 512 is +5.6 % (1260 ->
+                // 1330 TFLOP/s, profiles/r04_notes.md), 256 -> 512 still -3 %: the threshold is 512 input channels now
                 auto fill = [&](long long b) { return (double)b / (double)(((b + 255) / 256) * 256); };
                 const long long b512 = (long long)d.n * ceil_div(p->Dr, 4) * ceil_div(p->Hr, 4) * ceil_div(p->Wr, 32) * ceil_div(d.cout, 128);
-                const bool sk512 = sk_ok && p->Cin >= 1024 && p->Wr % 32 == 0 && p->Hr % 4 == 0 && p->Dr % 4 == 0 &&
+                const char* skm = getenv("CTSI_CONV_K32_SK512_MIN");   // tuning aid: least input channels for this form (A/B timing)
+                const bool sk512 = sk_ok && p->Cin >= (skm ? atoi(skm) : 512) && p->Wr % 32 == 0 && p->Hr % 4 == 0 && p->Dr % 4 == 0 &&
                                    fill(b512) < 0.8 && fill(2 * b512) >= 0.95 && !(sk && !strcmp(sk, "0"));
                 if ((sk && !strcmp(sk, "512") && sk_ok) || (sk512 && !(sk && (!strcmp(sk, "1") || !strcmp(sk, "plain"))))) {
                     p->halo3 = 7;

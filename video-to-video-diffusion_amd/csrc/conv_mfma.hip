@@ -109,7 +109,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long* s_rowoff = reinterpret_cast<long long*>(smem + NSTG * STAGE);
 
-    if (CTSI_DBG(p.dbg, 8)) return;
+    if (CTSI_DBG_RT(p.dbg, 8)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -424,7 +424,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
             slot = (slot + 1 == NSTG) ? 0 : slot + 1;
         }
     } else {
-        if (!(CTSI_DBG(p.dbg, 4)) && S > 0) stage(s_begin, smem);
+        if (!(CTSI_DBG_RT(p.dbg, 4)) && S > 0) stage(s_begin, smem);
         for (int s = 0; s < S; ++s) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -434,7 +434,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
         }
     }
     __syncthreads();  // every wave is done with the stage buffers
-    if (CTSI_DBG(p.dbg, 2)) return;
+    if (CTSI_DBG_RT(p.dbg, 2)) return;
     if constexpr (TM == 2 && TN == 2)          // (the host splits 128 x 128-tile plans only: keep the other forms' code lean)
     if (nsplit > 1) {
         // Split-K hand-off, S-way (conv3_halo_k32.hip has the 2-way form): every block parks its accumulators with agent-scope
@@ -676,7 +676,7 @@ conv_gather_mfma_kernel(const ConvKParams p) {
                 const int row = c / CPR, cc = c - row * CPR;
                 const long long off = s_rowoff[row];
                 const int co = n0 + cc * 8;
-                if (off >= 0 && co < p.Cout && !(CTSI_DBG(p.dbg, 1))) {
+                if (off >= 0 && co < p.Cout && !(CTSI_DBG_RT(p.dbg, 1))) {
                     const uint4 v = *reinterpret_cast<const uint4*>(s_tile + row * BN + cc * 8);
                     *reinterpret_cast<uint4*>(y + off + co) = v;
                 }

@@ -68,6 +68,11 @@ struct CtsiPerDeviceOnce {
 #define CTSI_DBG(flags, bit) (((bit) == 4096) ? ((flags) & 4096) : 0)
 #define CTSI_DBG_MASK 4096
 #endif
+// conv_gather_mfma_kernel keeps its four tests as RUN-TIME tests on a flags word that the host can only set in ablation builds
+// (ctsi_debug_flags() masks it to bit 4096 in the release library, and this kernel has no 4096 use): the branches are never taken
+// there, but compiling them out changed hipcc's register allocation of the 256 x 256 instantiation -- 380 -> 1616 bytes of
+// scratch per lane in the small-Cin form, the VAE decoder's first conv 0.44 -> 1.54 ms (round 4, caught by the per-op table).
+#define CTSI_DBG_RT(flags, bit) ((flags) & (bit))
 int ctsi_debug_flags();        // CTSI_DEBUG_FLAGS & CTSI_DBG_MASK, read per call (runtime.hip)
 int ctsi_debug_ksteps(int n);  // min(n, CTSI_DEBUG_KSTEPS) in ablation builds, n otherwise
 

@@ -105,7 +105,7 @@ extern "C" int ctsi_gn_colsum(const void* x, float* colsum, int n, int c, int d,
 // issues everything of a device on ONE stream (Ctx), which is what makes this safe; a caller that cannot promise that sets
 // CTSI_GN_FIN_SPLIT=0.
 #define GN_FIN_ROWS 2048
-#define GN_FIN_SMAX 16
+#define GN_FIN_SMAX 64
 #define GN_FIN_SLOTS 4
 __device__ double g_fin_part[GN_FIN_SLOTS][GN_FIN_ROWS][GN_FIN_SMAX][2];
 __device__ unsigned int g_fin_ticket[GN_FIN_SLOTS][GN_FIN_ROWS];
@@ -233,13 +233,14 @@ extern "C" int ctsi_gn_finalize(const float* colsum, double* sums, int n, int c,
     CTSI_CHECK_ARG(colsum && sums, "ctsi_gn_finalize: null argument");
     CTSI_CHECK_ARG(groups > 0 && c % groups == 0, "ctsi_gn_finalize: c=%d not divisible by groups=%d", c, groups);
     const int cpg = c / groups;
-    // slices: one per 8192 16-byte items of a (sample, group) (the vector path only), at most 16; scratch rows rotate over 4
+    // slices: one per 2048 16-byte items of a (sample, group) (the vector path only), at most 64; scratch rows rotate over 4
     // slots per call so that consecutive launches never share one
     int S = 1;
     static int call_no = 0;
     if ((cpg & 3) == 0 && (c_pad & 3) == 0 && nclass == 1 && (long long)n * groups <= GN_FIN_ROWS) {
         const long long items4 = (long long)tiles_per_sample * (cpg >> 2);
-        S = (int)(items4 / 8192);
+        S = (int)(items4 / 2048);       // (round 4: 2048 instead of 8192 items per slice, up to 64 slices: the VAE's 8-group norms gave
+                                        //  96 blocks of 256 KB each at full resolution -- 27 us per launch, latency-bound)
         if (S > GN_FIN_SMAX) S = GN_FIN_SMAX;
         if (S < 1) S = 1;
         static const char* fs = getenv("CTSI_GN_FIN_SPLIT");

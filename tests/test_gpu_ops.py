@@ -230,6 +230,39 @@ def test_narrow_plane_tiles_transposed_and_strided_forms(G, monkeypatch, kind, c
     assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("cout,dims", [(128, (1, 4, 16, 64)), (128, (2, 5, 11, 37)), (72, (1, 3, 9, 33)), (256, (1, 2, 8, 32))],
+                         ids=["aligned", "ragged_batch2", "cout72_padded", "cout256_two_ntiles"])
+def test_one_channel_stem_conv(G, monkeypatch, cout, dims):
+    """conv3_stem_kernel (csrc/conv3_stem.hip): the VAE encoder's first conv, a one-channel volume stored with 8 channels
+    (models/vae.py:27, 109), 27 taps as the K of one MFMA: against fp32 torch with the GroupNorm column sums, and against the
+    gather kernel's small-Cin form."""
+    n, d, h, w = dims
+    x = bf16_round(formula_input((n, 1, d, h, w), 1))
+    wt = bf16_round(_w((cout, 1, 3, 3, 3), 3))
+    b = formula_input((cout,), 4) * 0.1
+    ref = F.conv3d(x, wt, b, padding=1)
+    groups = 8
+    L = importlib.import_module("video-to-video-diffusion_amd.lib")
+    import ctypes as C
+    lib = L.get_lib()
+    desc = L.ConvDesc(0, 3, 3, 3, 1, 1, 1, 1, 1, n, 8, 0, cout, d, h, w, 0)
+    plan = C.c_void_p()
+    lib.conv_plan_create(C.byref(plan), C.byref(desc))
+    lib.conv_plan_set_weight_cin(plan, 1)
+    bm, bn, mode = C.c_int(), C.c_int(), C.c_int()
+    lib.conv_plan_config(plan, C.byref(bm), C.byref(bn), C.byref(mode))
+    lib.conv_plan_destroy(plan)
+    assert mode.value == 11
+    y, sums = G.run_conv(x, None, wt, b, c1_pad=8, cin_w=1, want_stats=True, groups=groups)
+    assert rel_l2(y, ref) < CONV_TOL
+    rg = ref.reshape(n, groups, -1).double()
+    assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+    assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
+    monkeypatch.setenv("CTSI_CONV_NO_STEM", "1")
+    y2, _ = G.run_conv(x, None, wt, b, c1_pad=8, cin_w=1)
+    assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
 DOWN_CASES = [
     # name, cin, cout, (n, d, h_in, w_in)
     ("aligned_128_128", 128, 128, (1, 4, 8, 64)),

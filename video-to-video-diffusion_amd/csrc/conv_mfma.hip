@@ -745,6 +745,8 @@ struct ctsi_conv_plan {
     int ds;         // halo3 == 7: the strided (3,4,4)/(1,2,2) Downsample form of the k32 kernel (conv3_halo_k32.hip, DS)
     int head2;      // halo3 == 6: conv3_head2_kernel (taps as the GEMM's N dimension) serves the launches that ask for no column sums
     int ksplit;     // halo3 == 7, tile 5: 2 = two blocks per (tile, n-tile), each half of the input-channel chunks (needs a workspace)
+    int stem;       // 1: conv3_stem_kernel (conv3_stem.hip: 3x3x3 conv of a one-channel volume stored with 8 channels); chosen by
+                    // ctsi_conv_plan_set_weight_cin(plan, 1)
     int stream1;    // > 0: conv1_stream_kernel (conv1_stream.hip: 1x1x1 conv + fused GroupNorm tail as a streaming pass), value = 16-cout
                     // tiles per n-tile; chosen by ctsi_conv_plan_set_stream_tail, never by ctsi_conv_plan_create
     int halo3;  // 3x3x3 halo-tile kernels: 2 = conv3_halo32_kernel (conv3_halo.hip: 4x2x32 / 4x4x16 / 3x4x16 tiles), 6 = few-cout
@@ -1283,6 +1285,7 @@ extern "C" int ctsi_conv_plan_out_dims(const ctsi_conv_plan* p, int* d, int* h, 
 }
 extern "C" size_t ctsi_conv_plan_weight_bytes(const ctsi_conv_plan* p) {
     if (!p) return 0;
+    if (p->stem) return ctsi_conv3_stem_weight_bytes(p->CoutPad);
     if (p->stream1) return (size_t)p->d.cout * p->Cin * 2;
     if (p->halo3 == 6)   // head kernels: conv3_head's image (8 weight rows when cout <= 8; + 1 KB: its last DMA piece is read whole),
         return head1_bytes(p) + (ctsi_conv3_head2_supported(p->Cin, p->d.cout) ? ctsi_conv3_head2_weight_bytes(p->d.cout) : 0);   // then conv3_head2's
@@ -1307,7 +1310,7 @@ extern "C" int ctsi_conv_plan_config(const ctsi_conv_plan* p, int* bm, int* bn, 
     CTSI_CHECK_ARG(p, "ctsi_conv_plan_config: null plan");
     if (bm) *bm = p->BM;
     if (bn) *bn = p->BN;
-    if (mode) *mode = p->stream1 ? 10 : (p->halo3 ? 2 + p->halo3 : (p->small ? 1 : (p->fast ? 2 : 0)));
+    if (mode) *mode = p->stem ? 11 : p->stream1 ? 10 : (p->halo3 ? 2 + p->halo3 : (p->small ? 1 : (p->fast ? 2 : 0)));
     if (p->stream1) {
         if (bm) *bm = 16;
         if (bn) *bn = p->stream1 * 16;
@@ -1337,12 +1340,34 @@ extern "C" int ctsi_conv_plan_set_stream_tail(ctsi_conv_plan* p, int on) {
 extern "C" int ctsi_conv_plan_set_weight_cin(ctsi_conv_plan* p, int cin_w) {
     CTSI_CHECK_ARG(p && cin_w > 0 && cin_w <= p->Cin, "ctsi_conv_plan_set_weight_cin: bad cin %d", cin_w);
     p->CinW = cin_w;
+    // a 3x3x3 stride-1 conv of a ONE-channel volume (the VAE encoder's first layer: the CT volume is stored with 8 channels,
+    // 7 of them padding) with >= 64 couts: the 27 taps become the K of one MFMA (conv3_stem.hip); CTSI_CONV_NO_STEM keeps the
+    // gather kernel's small-Cin form (A/B timing, tests)
+    const ctsi_conv_desc& d = p->d;
+    if (cin_w == 1 && !d.transposed && d.kd == 3 && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.pd == 1 && d.ph == 1 &&
+        d.pw == 1 && d.c2 == 0 && d.c1 == 8 && d.cout >= 64 && d.cout % 8 == 0 && !p->dshift && !getenv("CTSI_CONV_NO_STEM")) {
+        p->stem = 1;
+        p->halo3 = 0;
+        p->gsplit = 0;
+        p->linear = 0;
+        p->BM = 512;
+        p->BN = 128;
+        ctsi_conv3_stem_tile(&p->TD, &p->TH, &p->TW);
+        p->tilesD = ceil_div(p->Dr, p->TD);
+        p->tilesH = ceil_div(p->Hr, p->TH);
+        p->tilesW = ceil_div(p->Wr, p->TW);
+        p->tps = p->tilesD * p->tilesH * p->tilesW;
+        p->mtiles = d.n * p->tps;
+        p->CoutPad = ceil_div(d.cout, 128) * 128;
+        p->ntiles_n = p->CoutPad / 128;
+    }
     return CTSI_OK;
 }
 
 extern "C" int ctsi_conv_plan_pack_weights(const ctsi_conv_plan* p, const float* w, void* packed,
                                            void* stream) {
     CTSI_CHECK_ARG(p && w && packed, "ctsi_conv_plan_pack_weights: null argument");
+    if (p->stem) return ctsi_conv3_stem_pack(w, packed, p->d.cout, p->CoutPad, p->CinW, stream);
     if (p->stream1) return ctsi_conv1_stream_pack(w, packed, p->d.cout, p->Cin, p->CinW, p->stream1, stream);
     if (p->halo3 == 7)
         return ctsi_conv3_halo_k32_pack(w, packed, p->d.cout, p->CoutPad, p->Cin, p->CinW, p->BN, p->ds ? 2 : p->d.transposed,
@@ -1428,6 +1453,22 @@ extern "C" int ctsi_conv_fwd(const ctsi_conv_plan* p, const void* x1, const void
                        "ctsi_conv_fwd: bf16 output needs cout, cout_stride, c_off multiples of 8 "
                        "(cout=%d stride=%d off=%d)", p->d.cout, o->cout_stride, o->c_off);
     }
+    if (p->stem && o->mode == 0 && o->act == 0 && o->gn_x == nullptr) {
+        StemParams q;
+        memset(&q, 0, sizeof(q));
+        q.x = (const bf16_t*)x1;
+        q.w = (const bf16_t*)packed_w;
+        q.bias = bias;
+        q.y = (bf16_t*)o->y;
+        q.colsum = (float*)o->colsum;
+        q.cx = p->d.c1;
+        q.D = p->d.di; q.H = p->d.hi; q.W = p->d.wi;
+        q.Cout = p->d.cout; q.CoutPad = p->CoutPad;
+        q.cout_stride = o->cout_stride; q.c_off = o->c_off;
+        q.tilesD = p->tilesD; q.tilesH = p->tilesH; q.tilesW = p->tilesW; q.tps = p->tps; q.mtiles = p->mtiles;
+        return ctsi_conv3_stem_launch(&q, stream);
+    }
+    CTSI_CHECK_ARG(!p->stem, "ctsi_conv_fwd: a one-channel stem plan writes bf16 without activation or fused tail");
     if (p->stream1) {
         CTSI_CHECK_ARG(o->mode == 0 && o->act == 0 && o->colsum == nullptr,
                        "ctsi_conv_fwd: a streaming 1x1x1 plan writes bf16 without activation or column sums");

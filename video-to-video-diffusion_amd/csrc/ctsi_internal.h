@@ -172,6 +172,22 @@ extern "C" size_t ctsi_conv3_head2_weight_bytes(int cout);
 extern "C" int ctsi_conv3_head2_pack(const float* w, void* packed, int cout, int cin, int cin_w, void* stream);
 extern "C" int ctsi_conv3_head2_launch(const Conv3HaloParams* hp, int n, const void* packed, int out_mode, int act, long long sn,
                                        long long sc, long long sd, long long sh, long long sw, void* stream);
+// ---- conv3_stem.hip (3x3x3 conv of a one-channel volume: the VAE encoder's first layer), driven through the conv plan -------
+struct StemParams {
+    const bf16_t* x;          // bf16 NDHWC, cx channels per voxel, channel 0 is the volume
+    const bf16_t* w;          // packed [n-tile][cout tile j][lane][8]
+    const float* bias;
+    bf16_t* y;
+    float* colsum;            // [2][tiles][cout_pad] or NULL
+    int cx, D, H, W;
+    int Cout, CoutPad, cout_stride, c_off;
+    int tilesD, tilesH, tilesW, tps, mtiles;
+};
+extern "C" void ctsi_conv3_stem_tile(int* td, int* th, int* tw);
+extern "C" size_t ctsi_conv3_stem_weight_bytes(int cout_pad);
+extern "C" int ctsi_conv3_stem_pack(const float* w, void* packed, int cout, int cout_pad, int cin_w, void* stream);
+extern "C" int ctsi_conv3_stem_launch(const StemParams* q, void* stream);
+
 // ---- conv1_stream.hip (1x1x1 conv + fused GroupNorm tail, streaming), driven through the conv plan ---------
 struct Conv1StreamParams {
     const bf16_t* x1;

@@ -279,6 +279,14 @@ int ctsi_wgrad(const ctsi_wgrad_desc* desc, const void* r, const void* g, void* 
 int ctsi_weight_dgrad_layout(const float* w, float* out, int cout, int cin, int taps, int ci_off, int ci_cnt,
                              void* stream);
 
+/* Weight and bias gradients of MANY small pointwise layers (the proj_out / V layers of the TemporalAttention blocks, whose
+ * operands are depth-summed tensors of a few hundred rows) in ONE launch.  entries: device array of
+ *   { const bf16* x [rows][cin]; const bf16* dy [rows][cout]; float* dw [cout][dw_stride]; float* db or NULL;
+ *     int rows, cin, cout, dw_stride; float b_scale; int pad }                                     (56 bytes each)
+ * blocks: device array of { int entry, cout_tile, cin_tile, pad } -- one row per 64 x 64 tile of an entry's dW (16 bytes each).
+ * dw[co][ci] = sum_r dy[r][co] * x[r][ci] (WRITTEN, not accumulated), db[co] = b_scale * sum_r dy[r][co]; deterministic. */
+int ctsi_linear_wgrad_multi(const void* entries, const void* blocks, int n_blocks, void* stream);
+
 /* Backward of ctsi_gn_apply (GroupNorm [+SiLU] [+time bias] [+residual] [+SiLU]).  x: the tensor that was normalised,
  * dy: gradient of the output (depth-broadcast (n,1,h,w,c) tensor when dy_bcast_d), sums: the forward's fp64 statistics,
  * residual: the forward's residual input (needed when silu_post).  Writes g_buf = gradient of the GroupNorm output

@@ -803,3 +803,86 @@ extern "C" int ctsi_linear_bwd(const float* x, const float* w, const float* dy, 
     }
     return CTSI_OK;
 }
+
+// ==== weight + bias gradients of many SMALL pointwise layers in one launch ============================================
+// The 22 pointwise layers inside the 11 TemporalAttention blocks (proj_out and the V third of qkv: models/unet3d.py:152-153,
+// 185-190) act on depth-summed tensors of 144-2304 rows: their weight gradients were 22 x (split-K kernel + reduce pass) and
+// their bias gradients 22 x (partial + final channel sum) = 88 launches of 5-10 us, 14 TFLOP/s (0.9 ms per config-3 micro-step).
+// Their operands are tiny (<= 1.2 MB), so the training engine keeps them until the end of the backward pass and issues ONE
+// launch: a block owns a 64 x 64 tile of one layer's dW (and, in the first cin tile, 64 entries of db) and walks ALL rows in
+// order -- fp32 FMAs on bf16 operands staged through LDS, no split, no atomics: deterministic.
+struct LinGradEntry {
+    const bf16_t* x;     // [rows][cin]   layer input
+    const bf16_t* dy;    // [rows][cout]  output gradient
+    float* dw;           // [cout][dw_stride] (+ element offset applied by the host)
+    float* db;           // [cout] or NULL
+    int rows, cin, cout, dw_stride;
+    float b_scale;
+    int pad_;
+};
+struct LinGradBlock { int entry, ct, it, pad_; };
+
+__global__ void __launch_bounds__(256)
+linear_wgrad_multi_kernel(const LinGradEntry* __restrict__ entries, const LinGradBlock* __restrict__ blocks) {
+    __shared__ __attribute__((aligned(16))) bf16_t s_dy[32][64 + 8];   // (+8: rows 16 B apart mod 128 B)
+    __shared__ __attribute__((aligned(16))) bf16_t s_x[32][64 + 8];
+    const LinGradBlock b = blocks[blockIdx.x];
+    const LinGradEntry e = entries[b.entry];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int co0 = b.ct * 64, ci0 = b.it * 64;
+    const int lr = tid >> 3, lc = (tid & 7) * 8;                        // staging: row lr, 8 channels from lc
+    float acc[4][4], bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bs[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    }
+    for (int r0 = 0; r0 < e.rows; r0 += 32) {
+        const int r = r0 + lr;
+        uint4 vd = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
+        if (r < e.rows) {
+            if (co0 + lc < e.cout) vd = *reinterpret_cast<const uint4*>(e.dy + (long long)r * e.cout + co0 + lc);
+            if (ci0 + lc < e.cin) vx = *reinterpret_cast<const uint4*>(e.x + (long long)r * e.cin + ci0 + lc);
+        }
+        __syncthreads();
+        *reinterpret_cast<uint4*>(&s_dy[lr][lc]) = vd;
+        *reinterpret_cast<uint4*>(&s_x[lr][lc]) = vx;
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const uint2 d2 = *reinterpret_cast<const uint2*>(&s_dy[k][ty * 4]);
+            const uint2 x2 = *reinterpret_cast<const uint2*>(&s_x[k][tx * 4]);
+            const float dv[4] = {__uint_as_float(d2.x << 16), __uint_as_float(d2.x & 0xffff0000u), __uint_as_float(d2.y << 16),
+                                 __uint_as_float(d2.y & 0xffff0000u)};
+            const float xv[4] = {__uint_as_float(x2.x << 16), __uint_as_float(x2.x & 0xffff0000u), __uint_as_float(x2.y << 16),
+                                 __uint_as_float(x2.y & 0xffff0000u)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bs[i] += dv[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(dv[i], xv[j], acc[i][j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = co0 + ty * 4 + i;
+        if (co >= e.cout) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ci = ci0 + tx * 4 + j;
+            if (ci < e.cin) e.dw[(long long)co * e.dw_stride + ci] = acc[i][j];
+        }
+        if (e.db != nullptr && b.it == 0 && tx == 0) e.db[co] = bs[i] * e.b_scale;
+    }
+}
+
+// entries / blocks: device tables built by the caller (n_blocks rows of {entry, cout tile, cin tile}); channel counts multiples of 8
+extern "C" int ctsi_linear_wgrad_multi(const void* entries, const void* blocks, int n_blocks, void* stream) {
+    CTSI_CHECK_ARG(entries && blocks && n_blocks > 0, "ctsi_linear_wgrad_multi: bad arguments");
+    hipLaunchKernelGGL(linear_wgrad_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const LinGradEntry*)entries, (const LinGradBlock*)blocks);
+    CTSI_LAUNCH_CHECK();
+    return CTSI_OK;
+}

@@ -114,6 +114,7 @@ SIGNATURES = {
     "ctsi_wgrad_flops": (C.c_double, [C.POINTER(WgradDesc)], False),
     "ctsi_wgrad": (_i, [C.POINTER(WgradDesc), _vp, _vp, _vp, _sz, _vp, _ll, _ll, _ll, _f, _vp], True),
     "ctsi_weight_dgrad_layout": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp], True),
+    "ctsi_linear_wgrad_multi": (_i, [_vp, _vp, _i, _vp], True),
     "ctsi_gn_bwd_tiles": (_i, [_i, _i, _i], False),
     "ctsi_gn_bwd_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i], False),
     "ctsi_gn_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp, _vp, _vp,

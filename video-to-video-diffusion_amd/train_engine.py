@@ -20,6 +20,7 @@ GradScaler, gradient accumulation, clip_grad_norm_ and any torch optimizer work 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -43,6 +44,7 @@ class UNetTrainProgram(Program):
         dev = ctx.device
         vox = d * h * w
         self.tape: List[Callable[[], None]] = []
+        self._deferred_lin: List[tuple] = []     # small pointwise layers whose weight / bias gradients go into ONE launch at the end
         self.grads: Dict[int, torch.Tensor] = {}     # id(param) -> fp32 gradient buffer (maybe padded)
         self._need = dict(wgrad=16, gn=16, chsum=16)
         self._ws: Dict[str, Optional[torch.Tensor]] = dict(wgrad=None, gn=None, chsum=None)
@@ -154,10 +156,40 @@ class UNetTrainProgram(Program):
         self._emit(run_loss_bwd, "loss.bwd")
         for fn in reversed(self.tape):
             fn()
+        self._emit_deferred_lin()
         self._time_embed_bwd()
         self.finalize_layout()
         for key, need in self._need.items():
             self._ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+
+    def _emit_deferred_lin(self):
+        """ONE launch for the weight and bias gradients of every deferred pointwise layer (the 22 attention projections):
+        device tables of layers and of 64 x 64 dW tiles, built once."""
+        import struct
+        if not self._deferred_lin:
+            return
+        ents, blks, fl = [], [], 0.0
+        for i, (xa, ga, gw, gw_off, gb, gb_off, b_scale, rows, cin, cout, dw_stride) in enumerate(self._deferred_lin):
+            dbp = 0 if gb is None else gb.data_ptr() + 4 * gb_off
+            ents.append(struct.pack("<QQQQiiiifi", xa.ip.value, ga.ip.value, gw.data_ptr() + 4 * gw_off, dbp, rows, cin, cout,
+                                    dw_stride, b_scale, 0))
+            for ct in range((cout + 63) // 64):
+                for it in range((cin + 63) // 64):
+                    blks.append(struct.pack("<iiii", i, ct, it, 0))
+            fl += 2.0 * rows * cin * cout
+        dev = self.ctx.device
+        et = torch.frombuffer(bytearray(b"".join(ents)), dtype=torch.uint8).to(dev)
+        bt = torch.frombuffer(bytearray(b"".join(blks)), dtype=torch.uint8).to(dev)
+        self.keep.extend([et, bt])
+        lib, sptr, nb = self.lib, self.ctx.sptr, len(blks)
+
+        def run():
+            lib.linear_wgrad_multi(_ptr(et), _ptr(bt), nb, sptr)
+
+        self.flops += fl
+        self._emit(run, "attn.wgrad+bgrad.batched", fl, "linear_wgrad_multi")
+        for (xa, ga, *_rest) in self._deferred_lin:
+            self.release(ga)
 
     # ---- helpers ---------------------------------------------------------------------------------------------
     def _ws_ptr(self, key):
@@ -228,7 +260,7 @@ class UNetTrainProgram(Program):
 
     def _conv_bwd(self, name, wparam, bparam, x1, x2, g: Act, transposed, k, s, p, cout, need_dx,
                   w_rows=None, b_scale=1.0, gw: Optional[torch.Tensor] = None, gb: Optional[torch.Tensor] = None,
-                  gw_off=0, gb_off=0, w_src: Optional[Callable[[], torch.Tensor]] = None):
+                  gw_off=0, gb_off=0, w_src: Optional[Callable[[], torch.Tensor]] = None, defer_wb: bool = False):
         """Emit bias / weight / data gradient launches of one conv whose output gradient is `g`.
         gw/gb (+ element offsets) override the destination (used for the V slice of attention's qkv);
         w_src overrides the weight the data gradient uses (same slice)."""
@@ -242,8 +274,14 @@ class UNetTrainProgram(Program):
         if gb is None and bparam is not None:
             gb = self.grad_buf(bparam, rows_pad=g.c if g.c > bparam.shape[0] else None)
         rows = g.n * g.vox
+        if defer_wb:
+            # a small 1x1x1 layer (rows of a depth-summed tensor): weight and bias gradient join the batched launch at the end of
+            # the backward pass (ctsi_linear_wgrad_multi); x1 and g must stay alive until then
+            if transposed or T != 1 or x2 is not None:
+                raise CtsiError("internal: only plain pointwise layers can defer their weight gradient")
+            self._deferred_lin.append((x1, g, gw, gw_off, gb, gb_off, float(b_scale), rows, x1.c, g.c, wparam.shape[1]))
         # bias: channel sums of the output gradient
-        if gb is not None:
+        if gb is not None and not defer_wb:
             self._need["chsum"] = max(self._need["chsum"], 4 * lib.channel_sum_workspace_floats(rows, g.c))
             gp, gbp, gc = g.ip, C.c_void_p(gb.data_ptr() + 4 * gb_off), g.c
 
@@ -253,7 +291,7 @@ class UNetTrainProgram(Program):
             self._emit(run_b, name + ".bgrad")
         # weight
         srcs = [(x1, 0)] + ([(x2, x1.c)] if x2 is not None else [])
-        for xa, coff in srcs:
+        for xa, coff in ([] if defer_wb else srcs):
             if transposed:   # weight (cin, cout, T): R = layer input, G = output gradient
                 r_act, g_act = xa, g
                 sr, sg = cw_out * T, T
@@ -447,17 +485,18 @@ class UNetTrainProgram(Program):
 
             self._emit(run_dsum, "attn.bwd.depthsum")
             # proj_out: dW_p, db_p, du
+            defer = not os.environ.get("CTSI_TRAIN_NO_LIN_BATCH")     # (A/B timing, tests: one wgrad + bgrad launch pair per layer)
             self._conv_bwd("attn.proj", m.proj_out.weight, m.proj_out.bias, u, None, dP, False, (1, 1, 1), (1, 1),
-                           (0, 0, 0), c, True)
+                           (0, 0, 0), c, True, defer_wb=defer)
             du = u.grad
             # V third of qkv: dW_v, db_v (x D: the bias is added once per depth slice), d(xs)
             gqkv_w, gqkv_b = self.grad_buf(m.qkv.weight), self.grad_buf(m.qkv.bias)
             self._conv_bwd("attn.v", m.qkv.weight, m.qkv.bias, xs, None, du, False, (1, 1, 1), (1, 1), (0, 0, 0), c,
-                           True, b_scale=float(d), gw=gqkv_w, gb=gqkv_b, gw_off=2 * c * c, gb_off=2 * c, w_src=wv)
+                           True, b_scale=float(d), gw=gqkv_w, gb=gqkv_b, gw_off=2 * c * c, gb_off=2 * c, w_src=wv, defer_wb=defer)
             dxs = xs.grad
             # GroupNorm under the depth sum: dy is d(xs) broadcast over depth; + gy (the identity path)
             self._gn_bwd(x, dxs, True, slot, m.norm, gamma, beta, False, None, None, False, gy)
-            for a in (dP, du, dxs, gy):
+            for a in ((dxs, gy) if defer else (dP, du, dxs, gy)):      # (deferred: dP and du are read by the batched launch)
                 self.release(a)
             self.pool.put(dsum)
             u.grad = xs.grad = out.grad = None

@@ -39,7 +39,8 @@
 // LDS, no 2-byte LDS writes, no row re-reads.  Staged (round 2): the bf16 tile goes through LDS, packed row = cout.  The two forms
 // use different packed weight images (ctsi_conv3_halo_k32_pack's `direct`).  Same-box alternation of whole bench runs
 // (profiles/r04_epilogue_ab.log): 512-voxel tiles -1.8 % (plain), -2.1 % (ConvTranspose), -0.7 % (split-K), the 384-voxel split-K
-// form -4.3 %; the PLAIN 384-voxel tiles +3 % (slower) and their Downsample forms +-0: ctsi_conv3_halo_k32_direct() picks per form.
+// form -4.3 %; the 24- / 12-wide 384-voxel tiles -2 % (25 stitching windows: 46.7 -> 45.8 ms over their 20 launches); the PLAIN
+// 3x4x32 / 3x8x16 tiles +3 % / +1.5-2 % (slower) and their Downsample forms +-0: ctsi_conv3_halo_k32_direct() picks per form.
 // cout (within the block's n-tile) of accumulator column r16 of cout tile j
 template <int NJ, bool DIRECT>
 __device__ __forceinline__ int hk_col(int j, int r16) { return DIRECT ? r16 * NJ + j : j * 16 + r16; }
@@ -821,15 +822,15 @@ extern "C" int ctsi_conv3_halo_k32_pack(const float* w, void* packed, int cout, 
     return CTSI_OK;
 }
 
-// Which forms store straight from the accumulators (measured per form, see hk_col): the 512-voxel tiles in every form and the
-// 384-voxel split-K form of the plain conv; the other 384-voxel forms keep the staged epilogue.
+// Which forms store straight from the accumulators (measured per form, see hk_col): the 512-voxel tiles and the 24- / 12-wide
+// 384-voxel tiles in every form, and the 384-voxel split-K form of the plain conv; the other 384-voxel forms keep the staged epilogue.
 // (-DHK_STAGED_EPILOGUE, `make staged`: the staged epilogue everywhere, for A/B timing through CTSI_LIB.)
 extern "C" int ctsi_conv3_halo_k32_direct(int tile, int ksplit, int ds) {
 #ifdef HK_STAGED_EPILOGUE
     return 0;
 #else
-    const bool t512 = tile == 0 || tile == 2;
-    return (t512 || (tile == 5 && ksplit == 2 && !ds)) ? 1 : 0;
+    const bool t512 = tile == 0 || tile == 2, narrow = tile == 6 || tile == 7;
+    return (t512 || narrow || (tile == 5 && ksplit == 2 && !ds)) ? 1 : 0;
 #endif
 }
 
@@ -839,7 +840,7 @@ static void hk_launch(const Conv3HaloParams* hp, hipStream_t stream) {
 #ifdef HK_STAGED_EPILOGUE
     constexpr bool DIRECT = false;
 #else
-    constexpr bool DIRECT = TD * TH * TW == 512 || (SK && !DS);
+    constexpr bool DIRECT = TD * TH * TW == 512 || TW == 24 || TW == 12 || (SK && !DS);
 #endif
     auto k = conv3_halo_k32_kernel<TD, TH, TW, BN, UPS, TR, SK, DS, DIRECT>;
     static CtsiPerDeviceOnce attr_once;

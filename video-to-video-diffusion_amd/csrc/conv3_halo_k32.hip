@@ -293,6 +293,12 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
     // kg >> 1 = which of the unit's two taps, kg & 1 = which 8 of the tap's 16 channels
     const int r16 = lane & 15, kg = lane >> 4;
     const bool tap1 = kg >= 2;
+    // Which of an A tile's 16 voxels MFMA row rho computes is free to choose.  ConvTranspose form with the direct epilogue: voxel =
+    // 4 (rho & 3) + (rho >> 2), i.e. the four lane groups of one store instruction hold four CONSECUTIVE input voxels: -3.7 % on
+    // those launches (1.88 -> 1.81 ms for the U-Net's two).  The same permutation costs the plain and split-K forms 0-3 % (the lane
+    // order of the A fragments' ds_read_b128 changes): they keep voxel = rho (profiles/r04_notes.md).
+    constexpr bool VPERM = DIRECT && TR;
+    const int v16 = VPERM ? 4 * (r16 & 3) + (r16 >> 2) : r16;
     int a_lane, b_lane;
     int aoff[MA];                                            // byte offset of A tile i from the wave's first voxel: immediates for
     {                                                        // the 512-voxel tiles, wave-uniform registers for 384 (48 rows per
@@ -303,9 +309,9 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
         const int row0 = wave * 16 * MA;
         const int vbase = hv(row0);
         if constexpr (Cfg::STRADDLE) {                       // per-lane offsets: row r16 of A tile i may lie on the next W-line
-            const int v0 = hv(row0 + r16);
+            const int v0 = hv(row0 + v16);
 #pragma unroll
-            for (int i = 0; i < MA; ++i) aoff[i] = (hv(row0 + 16 * i + r16) - v0) * 32;
+            for (int i = 0; i < MA; ++i) aoff[i] = (hv(row0 + 16 * i + v16) - v0) * 32;
             a_lane = v0 * 32 + (kg & 1) * 16;
         } else {
 #pragma unroll
@@ -315,7 +321,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
                 else
                     aoff[i] = (hv(row0 + 16 * i) - vbase) * 32;
             }
-            a_lane = (vbase + r16) * 32 + (kg & 1) * 16;
+            a_lane = (vbase + v16) * 32 + (kg & 1) * 16;
         }
         b_lane = OFF_W + (kg >> 1) * TAP_BYTES + r16 * 32 + (kg & 1) * 16;
     }
@@ -600,7 +606,8 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
 #pragma unroll
     for (int i = 0; i < MA; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) vbits |= (unsigned)(s_rowoff[wave * 16 * MA + 16 * i + 4 * kg + q] >= 0) << (4 * i + q);
+        for (int q = 0; q < 4; ++q)
+            vbits |= (unsigned)(s_rowoff[wave * 16 * MA + 16 * i + (VPERM ? 4 * q + kg : 4 * kg + q)] >= 0) << (4 * i + q);
     // VALU per accumulator: half a v_cvt_pk_bf16_f32 (rows q, q + 1 of one cout share it), one 2-byte LDS write, and for the
     // column sums one add + one fma; the validity select only in waves that own rows outside the volume (ragged tiles).
     auto tile_out = [&](auto masked_tag, auto sums_tag) {
@@ -658,7 +665,7 @@ conv3_halo_k32_kernel(const Conv3HaloParams p) {
             for (int i = 0; i < MA; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const long long off = s_rowoff[wave * 16 * MA + 16 * i + 4 * kg + q];
+                    const long long off = s_rowoff[wave * 16 * MA + 16 * i + (VPERM ? 4 * q + kg : 4 * kg + q)];
                     if (SUMS) {
                         const bool live = !MASKED || ((vbits >> (4 * i + q)) & 1u);
 #pragma unroll

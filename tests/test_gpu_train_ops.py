@@ -346,6 +346,42 @@ def test_gn_backward_vs_autograd(G, name, c, groups, dims, silu_pre, res, silu_p
         assert rel_l2(dtb[:, :c].cpu(), tb.grad) <= 5e-3
 
 
+def test_batched_small_linear_gradients(G):
+    """ctsi_linear_wgrad_multi: weight and bias gradients of several small pointwise layers in one launch (the attention
+    projections of the training path), against fp32 torch on the same bf16 operands: ragged row counts, channel counts that
+    are not multiples of the 64 x 64 tile, a scaled bias gradient, a dW with a wider row stride, a layer without bias."""
+    import struct
+    cx = G.ctx()
+    specs = [(300, 256, 256, 256, 1.0, True), (77, 72, 40, 96, 48.0, True), (1000, 512, 128, 512, 1.0, False)]   # rows, cin, cout, dw_stride, b_scale, bias
+    ents, blks, keep, want = [], [], [], []
+    for i, (rows, cin, cout, dws, bsc, has_b) in enumerate(specs):
+        x = bf16_round(formula_input((rows, cin), 30 + i))
+        dy = bf16_round(formula_input((rows, cout), 40 + i))
+        xd, dyd = x.to(DEV).to(torch.bfloat16).contiguous(), dy.to(DEV).to(torch.bfloat16).contiguous()
+        dw = torch.full((cout, dws), float("nan"), dtype=torch.float32, device=DEV)
+        db = torch.full((cout,), float("nan"), dtype=torch.float32, device=DEV)
+        keep += [xd, dyd, dw, db]
+        ents.append(struct.pack("<QQQQiiiifi", xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr() if has_b else 0, rows, cin,
+                                cout, dws, bsc, 0))
+        for ct in range((cout + 63) // 64):
+            for it in range((cin + 63) // 64):
+                blks.append(struct.pack("<iiii", i, ct, it, 0))
+        want.append((dy.double().t() @ x.double(), dy.double().sum(0) * bsc, dw, db, cin, has_b))
+    et = torch.frombuffer(bytearray(b"".join(ents)), dtype=torch.uint8).to(DEV)
+    bt = torch.frombuffer(bytearray(b"".join(blks)), dtype=torch.uint8).to(DEV)
+    with cx.scope():
+        cx.lib.linear_wgrad_multi(G._ptr(et), G._ptr(bt), len(blks), cx.sptr)
+        cx.lib.linear_wgrad_multi(G._ptr(et), G._ptr(bt), len(blks), cx.sptr)      # written, not accumulated: a second launch changes nothing
+    torch.cuda.synchronize()
+    for w_ref, b_ref, dw, db, cin, has_b in want:
+        assert rel_l2(dw[:, :cin].cpu().double(), w_ref) < 1e-5
+        assert torch.isnan(dw[:, cin:]).all()                      # columns beyond cin untouched
+        if has_b:
+            assert rel_l2(db.cpu().double(), b_ref) < 1e-5
+        else:
+            assert torch.isnan(db).all()
+
+
 def test_channel_sum_add_and_convert(G):
     cx = G.ctx()
     x = bf16_round(formula_input((3000, 40), 1))

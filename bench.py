@@ -46,7 +46,7 @@ LEGACY163_CFG = {  # the flat config behind the "163 M-param U-Net" of the refer
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable with a float4 copy)
 PMC_TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")   # written by tools/pmc_traffic.py (records its commit)
-PMC_TRAFFIC_TRAIN_FILE = os.path.join("profiles", "r03_pmc_traffic_train.json")   # the same over tools/profile_train.py
+PMC_TRAFFIC_TRAIN_FILE = os.path.join("profiles", "r04_pmc_traffic_train.json")   # the same over tools/profile_train.py
 
 
 def parse():
@@ -416,10 +416,13 @@ def bench_train(args, pkg, E, model, ctx, dev, rank, world, dist):
             traffic_source = None
             try:  # HBM bytes per launch from rocprofv3 --pmc passes over tools/profile_train.py (tools/pmc_traffic.py); null
                 pj = json.load(open(os.path.join(ROOT, PMC_TRAFFIC_TRAIN_FILE)))   # when no file of this round exists
-                ent = max((v for k_, v in pj["kernels"].items() if k_.startswith("conv_wgrad")),
-                          key=lambda v: v["launches_FETCH_SIZE"])
-                traffic = ent["hbm_bytes_per_launch"]
-                traffic_source = {"file": PMC_TRAFFIC_TRAIN_FILE, "commit": pj.get("commit"), "method": pj.get("method")}
+                fam = {k_: v for k_, v in pj["kernels"].items() if k_.startswith("conv_wgrad")}
+                main = sum(v["launches_FETCH_SIZE"] for k_, v in fam.items() if "reduce" not in k_)
+                # bytes of the whole family (the split-K reduce passes included) per weight-gradient kernel launch
+                traffic = sum(v["hbm_bytes_per_launch"] * v["launches_FETCH_SIZE"] for v in fam.values()) / main
+                traffic_source = {"file": PMC_TRAFFIC_TRAIN_FILE, "commit": pj.get("commit"), "method": pj.get("method"),
+                                  "per": "weight-gradient kernel launch, its split-K reduce pass included (family total / "
+                                         f"{main} launches in the counter run)"}
             except Exception:
                 pass
             ach = wg[1] / (wg[2] * 1e-3) / 1e12

@@ -205,6 +205,45 @@ def test_conv3_halo_k32_narrow_plane_tiles(G, monkeypatch, name, c1, c2, cout, d
     assert float((y - y2).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("c1,c2,cout,dims", [(256, 0, 256, (2, 6, 8, 24)), (512, 0, 512, (2, 16, 12, 12)), (128, 128, 72, (1, 11, 10, 12))],
+                         ids=["w24_256_256", "w12_512_512", "w12_concat_ragged"])
+def test_narrow_plane_tiles_split_k(G, monkeypatch, c1, c2, cout, dims):
+    """2-way split-K on the 4x4x24 / 8x4x12 tiles (config-3 training shapes: B = 4 leaves the 24- and 12-wide levels 2.25 / 1.1 rounds
+    of blocks): the plan asks for the hand-off workspace, results against fp32 torch with the GroupNorm column sums, equal to the
+    one-block-per-tile form up to the fp32 summation order, and bit-stable over repeated launches."""
+    L = importlib.import_module("video-to-video-diffusion_amd.lib")
+    import ctypes as C
+    n, d, h, w = dims
+    x1 = bf16_round(formula_input((n, c1, d, h, w), 1))
+    x2 = bf16_round(formula_input((n, c2, d, h, w), 2)) if c2 else None
+    x = torch.cat([x1, x2], 1) if c2 else x1
+    wt = bf16_round(_w((cout, c1 + c2, 3, 3, 3), 3))
+    b = formula_input((cout,), 4) * 0.1
+    ref = F.conv3d(x, wt, b, padding=1)
+    monkeypatch.setenv("CTSI_CONV_K32_NARROW", "1")
+    monkeypatch.setenv("CTSI_CONV_K32_NARROW_SK", "1")
+    lib = L.get_lib()
+    desc = L.ConvDesc(0, 3, 3, 3, 1, 1, 1, 1, 1, n, c1, c2, cout, d, h, w, 0)
+    plan = C.c_void_p()
+    lib.conv_plan_create(C.byref(plan), C.byref(desc))
+    pbm, pbn, mode = C.c_int(), C.c_int(), C.c_int()
+    lib.conv_plan_config(plan, C.byref(pbm), C.byref(pbn), C.byref(mode))
+    ws = lib.conv_plan_workspace_bytes(plan)
+    lib.conv_plan_destroy(plan)
+    assert (pbm.value, mode.value) == (384, 9) and ws > 0
+    groups = 8
+    y, sums = G.run_conv(x1, x2, wt, b, want_stats=True, groups=groups)
+    assert rel_l2(y, ref) < CONV_TOL
+    rg = ref.reshape(n, groups, -1).double()
+    assert torch.allclose(sums[..., 0], rg.sum(-1), rtol=1e-3, atol=1e-2 * math.sqrt(rg.shape[-1]))
+    assert torch.allclose(sums[..., 1], (rg * rg).sum(-1), rtol=2e-3)
+    y_again, sums_again = G.run_conv(x1, x2, wt, b, want_stats=True, groups=groups)
+    assert torch.equal(y, y_again) and torch.equal(sums, sums_again)
+    monkeypatch.setenv("CTSI_CONV_K32_NARROW_SK", "0")
+    y1, _ = G.run_conv(x1, x2, wt, b)
+    assert float((y - y1).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("kind,cin,cout,dims", [("up", 128, 128, (1, 8, 8, 24)), ("up", 256, 128, (2, 16, 8, 12)),
                                                 ("down", 128, 128, (1, 8, 16, 48)), ("down", 64, 192, (2, 16, 8, 24))],
                          ids=["convT_in24", "convT_in12_batch2", "down_out24", "down_out12_batch2"])

@@ -865,9 +865,16 @@ extern "C" int ctsi_conv3_halo_k32_launch(const Conv3HaloParams* hp, int tile /*
                                           int bn, void* stream) {
     CTSI_CHECK_ARG(bn == 128 && (tile == 0 || tile == 2 || tile == 3 || tile == 5 || tile == 6 || tile == 7),
                    "ctsi_conv3_halo_k32_launch: bad BN %d / tile %d", bn, tile);
-    if (tile == 6 || tile == 7) {   // 384-voxel tiles for 24- / 12-wide planes (no split-K form)
-        CTSI_CHECK_ARG(hp->ksplit != 2 && !(hp->ds && hp->tr), "ctsi_conv3_halo_k32_launch: tile %d has no split-K form", tile);
-        if (hp->ds) {
+    if (tile == 6 || tile == 7) {   // 384-voxel tiles for 24- / 12-wide planes (2-way split-K for the plain conv only)
+        CTSI_CHECK_ARG(!(hp->ds && hp->tr) && !(hp->ksplit == 2 && (hp->ds || hp->tr)),
+                       "ctsi_conv3_halo_k32_launch: tile %d has no split-K form for strided / transposed layers", tile);
+        if (hp->ksplit == 2) {
+            CTSI_CHECK_ARG(hp->sk_ws && hp->sk_sync && hp->nchunks % 8 == 0, "ctsi_conv3_halo_k32_launch: split-K needs its workspace");
+            if (tile == 6)
+                hk_launch<4, 4, 24, 128, 2, false, true>(hp, (hipStream_t)stream);
+            else
+                hk_launch<8, 4, 12, 128, 2, false, true>(hp, (hipStream_t)stream);
+        } else if (hp->ds) {
             CTSI_CHECK_ARG(hp->Hi == 2 * hp->Ho && hp->Wi == 2 * hp->Wo && hp->C2 == 0 && hp->nchunks % 4 == 0,
                            "ctsi_conv3_halo_k32_launch: the Downsample form needs even input planes and one source");
             if (tile == 6)

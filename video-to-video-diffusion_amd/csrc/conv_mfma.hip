@@ -1081,15 +1081,21 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             const char* nw = getenv("CTSI_CONV_K32_NARROW");
             const bool off = nw && !strcmp(nw, "0"), force = nw && !strcmp(nw, "1");
             struct { int td, th, tw, code; } cand[2] = {{4, 4, 24, 6}, {8, 4, 12, 7}};
+            // 2-way split-K on these tiles where it fills the CUs better (B = 4, 48 x 24^2 x 256 couts: 576 blocks = 2.25 rounds ->
+            // 1152 = 4.5; 48 x 12^2 x 512 couts: 288 -> 576); CTSI_CONV_K32_NARROW_SK = 0 / 1: never / wherever K allows
+            const char* nsk = getenv("CTSI_CONV_K32_NARROW_SK");
+            const bool nsk_ok = p->Cin % 128 == 0 && d.c1 % 16 == 0 && d.c2 % 16 == 0 && !(nsk && !strcmp(nsk, "0"));
             for (auto& c : cand) {
                 if (off || p->halo3 == 6 || p->Wr % c.tw != 0 || p->Wr % 16 == 0) continue;
-                if (force || sc(c.td, c.th, c.tw, 1.07, 1) > 1.05 * cur) {
+                const double s1 = sc(c.td, c.th, c.tw, 1.07, 1), s2 = nsk_ok ? sc(c.td, c.th, c.tw, 1.07, 2) : 0.0;
+                const bool sk2 = nsk_ok && ((nsk && !strcmp(nsk, "1")) || s2 > 1.1 * s1);
+                if (force || (sk2 ? s2 : s1) > 1.05 * cur) {
                     p->halo3 = 7;
                     p->BM = 384;
                     p->BN = 128;
                     p->h32_w16 = 0;
                     p->m512_w16 = c.code;
-                    p->ksplit = 0;
+                    p->ksplit = sk2 ? 2 : 0;
                     break;
                 }
             }

@@ -11,6 +11,7 @@ ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--hw", type=int, default=48)
 ap.add_argument("--depth", type=int, default=48)
 ap.add_argument("--repeats", type=int, default=2)
+ap.add_argument("--by-flops", action="store_true", help="split the conv rows by the layer's GFLOP as well (tells the channel counts apart)")
 a = ap.parse_args()
 pkg = importlib.import_module("video-to-video-diffusion_amd")
 E = importlib.import_module("video-to-video-diffusion_amd.engine")
@@ -33,10 +34,12 @@ agg = {}
 for i, (name, kern, fl, ms) in enumerate(prof):
     phase = "F" if i < prog.n_fwd else "B"
     key = (phase, name if not kern.startswith("conv_mfma") else name.split(".")[-1] + ":" + kern)
+    if a.by_flops and kern.startswith("conv_mfma"):
+        key = (phase, key[1] + f" {fl / 1e9:.0f}G")
     g = agg.setdefault(key, [0, 0.0, 0.0])
     g[0] += 1; g[1] += fl; g[2] += ms
 tot = sum(v[2] for v in agg.values())
 print(f"total {tot:.2f} ms, {prog.flops / 1e12:.2f} TFLOP, pool {prog.pool.total_bytes / 2**30:.2f} GiB")
-for (phase, name), v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:40]:
+for (phase, name), v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:60 if a.by_flops else 40]:
     tf = f"{v[1] / (v[2] * 1e-3) / 1e12:7.0f} TF" if v[1] else "          "
     print(f"{phase} {name:42s} n={v[0]:4d} {v[2]:8.3f} ms {100 * v[2] / tot:5.1f}% {tf}")

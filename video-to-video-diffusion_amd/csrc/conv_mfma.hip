@@ -1023,9 +1023,15 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
                     const double useful = (double)rows * d.n / ((double)t * 384);
                     return useful * (double)b / (double)(((b + 255) / 256) * 256) * 1.1;
                 };
+                // (round 4: not below 256 input channels -- a half-K block of a 128-channel layer walks 4 chunks, and its prologue,
+                //  hand-off and epilogue cost more than the better fill returns: config-3 128 -> 128 @ 4 x 48^3 0.408 ms as
+                //  2304 half-K blocks of 3x8x16, 0.331 ms as 864 blocks of 4x8x16; 256 -> 256 equal either way; profiles/r04_notes.md.
+                //  CTSI_CONV_K32_SK384_MIN: that threshold, for A/B timing)
+                const char* skc = getenv("CTSI_CONV_K32_SK384_MIN");
                 const bool sk_ok = p->Cin % 128 == 0 && d.c1 % 16 == 0 && d.c2 % 16 == 0;
+                const bool sk_deep = p->Cin >= (skc ? atoi(skc) : 256);
                 const double cur2 = use384 ? score(3, 4, 32, 1.1) : cur;
-                bool use_sk = sk_ok && score_sk() > cur2;
+                bool use_sk = sk_ok && sk_deep && score_sk() > cur2;
                 if (sk && !strcmp(sk, "0")) use_sk = false;
                 if (sk && !strcmp(sk, "1") && sk_ok) use_sk = true;
                 // 2-way split-K on the 4x4x32 tile: pays where the 512-voxel grid fills the CUs badly AND K is deep enough to
@@ -1084,11 +1090,13 @@ extern "C" int ctsi_conv_plan_create(ctsi_conv_plan** out, const ctsi_conv_desc*
             // 2-way split-K on these tiles where it fills the CUs better (B = 4, 48 x 24^2 x 256 couts: 576 blocks = 2.25 rounds ->
             // 1152 = 4.5; 48 x 12^2 x 512 couts: 288 -> 576); CTSI_CONV_K32_NARROW_SK = 0 / 1: never / wherever K allows
             const char* nsk = getenv("CTSI_CONV_K32_NARROW_SK");
+            const char* skc = getenv("CTSI_CONV_K32_SK384_MIN");
             const bool nsk_ok = p->Cin % 128 == 0 && d.c1 % 16 == 0 && d.c2 % 16 == 0 && !(nsk && !strcmp(nsk, "0"));
+            const bool nsk_deep = p->Cin >= (skc ? atoi(skc) : 256);
             for (auto& c : cand) {
                 if (off || p->halo3 == 6 || p->Wr % c.tw != 0 || p->Wr % 16 == 0) continue;
                 const double s1 = sc(c.td, c.th, c.tw, 1.07, 1), s2 = nsk_ok ? sc(c.td, c.th, c.tw, 1.07, 2) : 0.0;
-                const bool sk2 = nsk_ok && ((nsk && !strcmp(nsk, "1")) || s2 > 1.1 * s1);
+                const bool sk2 = nsk_ok && ((nsk && !strcmp(nsk, "1")) || (nsk_deep && s2 > 1.1 * s1));
                 if (force || (sk2 ? s2 : s1) > 1.05 * cur) {
                     p->halo3 = 7;
                     p->BM = 384;

@@ -63,6 +63,19 @@ def test_conv_plan_geometry_and_flops(lib):
     lib.conv_plan_config(p2, C.byref(bm), C.byref(bn), C.byref(mode))   # split-K (768 half-K blocks = 3 rounds; direct-store epilogue)
     assert (bm.value, bn.value, mode.value) == (512, 128, 9) and lib.conv_plan_workspace_bytes(p2) > 0
     lib.conv_plan_destroy(p2)
+    # config-3 training shapes (B = 4, latent 48^3): the 24- / 12-wide levels take the exact-fit 4x4x24 / 8x4x12 tiles as two half-K
+    # blocks per tile (576 / 288 one-block tiles would be 2.25 / 1.1 rounds of the CUs); a 128-channel layer is never split
+    # (4 chunks per half: 0.408 vs 0.331 ms measured) and runs whole-K on the 4x8x16 tile (48 = 3 x 16)
+    for kw, want_bm, split in ((dict(n=4, c1=256, cout=256, hi=24, wi=24), 384, True),
+                               (dict(n=4, c1=512, cout=512, hi=12, wi=12), 384, True),
+                               (dict(n=4, c1=128, cout=128, hi=48, wi=48), 512, False),
+                               (dict(n=4, c1=256, c2=128, cout=128, hi=48, wi=48), 384, True),      # 3x8x16, K = 384 channels
+                               (dict(n=1, c1=256, cout=256, hi=24, wi=24), 384, False)):            # config 1: one round either way
+        p2 = _plan(lib, **kw)
+        lib.conv_plan_config(p2, C.byref(bm), C.byref(bn), C.byref(mode))
+        assert (bm.value, bn.value, mode.value) == (want_bm, 128, 9), (kw, bm.value, mode.value)
+        assert (lib.conv_plan_workspace_bytes(p2) > 0) == split, kw
+        lib.conv_plan_destroy(p2)
     lib.conv_plan_config(p, C.byref(bm), C.byref(bn), C.byref(mode))
     assert lib.conv_plan_tiles(p) == 48 * 128 * 128 // bm.value and lib.conv_plan_cout_pad(p) == 128
     assert lib.conv_plan_weight_bytes(p) == 128 * 27 * 128 * 2       # 8 chunks x 27 taps = 216 entries = 54 whole steps

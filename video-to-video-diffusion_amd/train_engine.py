@@ -50,6 +50,10 @@ class UNetTrainProgram(Program):
         self._ws: Dict[str, Optional[torch.Tensor]] = dict(wgrad=None, gn=None, chsum=None)
         self.params = [p for p in unet.parameters()]
         self.track_module(unet)
+        # every parameter-gradient buffer is a piece of ONE fp32 arena, so that the hand-over to autograd is one copy instead of
+        # one per parameter (333 launches, 1.6 ms of a config-3 micro-step); the slack takes the row padding of the conv layouts
+        self._garena = self.persistent((sum(p.numel() for p in self.params) + (16 << 20),), torch.float32, zero=True)
+        self._garena_used = 0
         for p in self.params:
             if not p.is_cuda:
                 raise CtsiError("training runs on the HIP engine: move the model to a ROCm device first")
@@ -92,8 +96,8 @@ class UNetTrainProgram(Program):
         self.tbias = self.persistent((n, self.total_out), torch.float32, zero=True)
         self.d_tbias = self.persistent((n, self.total_out), torch.float32, zero=True)
         self.te_scratch = self.persistent((n * (self.dim + 2 * self.time_dim),), torch.float32)
-        self.g_w_all = self.persistent((self.total_out, self.time_dim), torch.float32, zero=True)
-        self.g_b_all = self.persistent((self.total_out,), torch.float32, zero=True)
+        self.g_w_all = self.grad_alloc((self.total_out, self.time_dim))
+        self.g_b_all = self.grad_alloc((self.total_out,))
         self.g_temb = self.persistent((n, self.time_dim), torch.float32, zero=True)
         self.g_lin1 = self.persistent((n, self.time_dim), torch.float32, zero=True)
 
@@ -195,13 +199,24 @@ class UNetTrainProgram(Program):
     def _ws_ptr(self, key):
         return C.c_void_p(self._ws[key].data_ptr())
 
+    def grad_alloc(self, shape) -> torch.Tensor:
+        """A zeroed fp32 gradient buffer: a 256-byte-aligned piece of the arena (a separate allocation once the arena is full)."""
+        numel = 1
+        for v in shape:
+            numel *= int(v)
+        if self._garena_used + numel > self._garena.numel():
+            return self.persistent(tuple(shape), torch.float32, zero=True)
+        g = self._garena[self._garena_used:self._garena_used + numel].view(tuple(shape))
+        self._garena_used += (numel + 63) // 64 * 64
+        return g
+
     def grad_buf(self, p: torch.Tensor, rows_pad: Optional[int] = None) -> torch.Tensor:
         g = self.grads.get(id(p))
         if g is None:
             shape = list(p.shape)
             if rows_pad is not None and rows_pad > shape[0]:
                 shape[0] = rows_pad
-            g = self.persistent(tuple(shape), torch.float32, zero=True)
+            g = self.grad_alloc(shape)
             self.grads[id(p)] = g
         return g
 
@@ -579,6 +594,31 @@ class UNetTrainProgram(Program):
         return out
 
 
+def _clone_grads(grads: List[torch.Tensor]) -> List[torch.Tensor]:
+    """Copies of the program's gradient buffers for autograd to own (the program overwrites its buffers in the next backward).
+    Buffers that share a storage -- the program's gradient arena -- are copied as ONE range and returned as views of the copy
+    at the same offsets; a storage whose members cover less than half of the range they span is copied tensor by tensor."""
+    if os.environ.get("CTSI_TRAIN_NO_GRAD_ARENA"):          # A/B timing: one copy per parameter, as before round 4
+        return [g.clone() for g in grads]
+    groups: Dict[int, List[int]] = {}
+    for i, g in enumerate(grads):
+        groups.setdefault(g.untyped_storage().data_ptr(), []).append(i)
+    out: List[Optional[torch.Tensor]] = [None] * len(grads)
+    for idx in groups.values():
+        g0 = grads[idx[0]]
+        lo = min(grads[i].storage_offset() for i in idx)
+        hi = max(grads[i].storage_offset() + grads[i].numel() for i in idx)
+        dense = all(grads[i].is_contiguous() and grads[i].dtype == g0.dtype for i in idx)
+        if len(idx) == 1 or not dense or (hi - lo) > 2 * sum(grads[i].numel() for i in idx):
+            for i in idx:
+                out[i] = grads[i].clone()
+            continue
+        flat = torch.empty(0, dtype=g0.dtype, device=g0.device).set_(g0.untyped_storage(), lo, (hi - lo,)).clone()
+        for i in idx:
+            out[i] = flat.as_strided(grads[i].shape, grads[i].stride(), grads[i].storage_offset() - lo)
+    return out
+
+
 class _TrainStep(torch.autograd.Function):
     """loss = training loss of one batch; backward runs the engine's backward launches and hands the parameter
     gradients to autograd (which accumulates them into .grad like any other op)."""
@@ -596,8 +636,7 @@ class _TrainStep(torch.autograd.Function):
     def backward(fctx, grad_out):
         prog = fctx.prog
         with prog.ctx.scope():
-            grads = prog.run_backward(grad_out, fctx.generation)
-            grads = [g.clone() for g in grads]
+            grads = _clone_grads(prog.run_backward(grad_out, fctx.generation))
         return (None,) * 7 + tuple(grads)
 
 

@@ -34,7 +34,7 @@ agg = {}
 for i, (name, kern, fl, ms) in enumerate(prof):
     phase = "F" if i < prog.n_fwd else "B"
     key = (phase, name if not kern.startswith("conv_mfma") else name.split(".")[-1] + ":" + kern)
-    if a.by_flops and kern.startswith("conv_mfma"):
+    if a.by_flops and (kern.startswith("conv_mfma") or "wgrad" in name):
         key = (phase, key[1] + f" {fl / 1e9:.0f}G")
     g = agg.setdefault(key, [0, 0.0, 0.0])
     g[0] += 1; g[1] += fl; g[2] += ms
